@@ -1,0 +1,227 @@
+// K3 / K3v / K4 / CLIP attention: flash-style softmax(scale QK^T [+causal]) V on fp16 MFMA (gfx950).
+// (include/fie.h: fie_attention_f16)
+//
+// Structure (wave64, v_mfma_f32_16x16x32_f16):
+//   * block = 4 waves; each wave owns QF x 16 query rows and keeps their Q fragments in registers;
+//     K and V tiles of KT keys are staged once per block in LDS (128-B-chunk XOR swizzle) and shared by the waves.
+//   * scores are computed TRANSPOSED, S^T = K Q^T (A operand = K rows, B operand = Q), so a lane holds one query
+//     column: the softmax row statistics are lane-local (+2 xor-shuffles over the 4 lane groups) and the fp16 P^T
+//     fragment is directly the B operand of O^T = V^T P^T.  V^T fragments come from the row-major V tile with
+//     ds_read_b64_tr_b16 (hardware transpose read), key order permuted consistently on both operands.
+//   * O^T accumulators: lane holds 4 consecutive d of one query -> the online-softmax rescale is lane-local and the
+//     output store is 8 bytes per lane.
+#include "fie_internal.h"
+
+namespace {
+
+struct AttnArgs {
+    const half_t* Q; int64_t ldq;
+    const half_t* K; int64_t ldk;
+    const half_t* V; int64_t ldv;
+    half_t* O; int64_t ldo;
+    int H, Tq, Tk;
+    float scale_log2;
+    int causal;
+};
+
+template <int D>
+__device__ __forceinline__ int kv_off(int row, int chunk) {
+    // row-major [KT][D] fp16, 16-byte chunks XOR-swizzled in their low 3 bits
+    return row * D + ((chunk ^ (row & 7)) << 3);
+}
+
+template <int D, int QF, int KT>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+    constexpr int KF = KT / 16;        // key fragments per tile
+    constexpr int DK = D / 32;         // k-steps of the QK^T product
+    constexpr int DF = D / 16;         // output d fragments
+    constexpr int PS = KT / 32;        // k-steps of the PV product
+    constexpr int CH = D / 8;          // 16-byte chunks per row
+    extern __shared__ __attribute__((aligned(16))) half_t smem[];
+    half_t* sk = smem;
+    half_t* sv = smem + KT * D;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (64 * QF) + wave * (16 * QF);
+
+    const half_t* Qb = p.Q + (int64_t)b * p.Tq * p.ldq + h * D;
+    const half_t* Kb = p.K + (int64_t)b * p.Tk * p.ldk + h * D;
+    const half_t* Vb = p.V + (int64_t)b * p.Tk * p.ldv + h * D;
+
+    // Q fragments (B operand of S^T): lane holds Q[q = q0 + qf*16 + fr][d = kk*32 + fq*8 .. +7]
+    f16x8 qf_[QF][DK];
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        const int q = q0 + a * 16 + fr;
+#pragma unroll
+        for (int kk = 0; kk < DK; ++kk)
+            qf_[a][kk] = q < p.Tq ? *reinterpret_cast<const f16x8*>(Qb + (int64_t)q * p.ldq + kk * 32 + fq * 8) : zero8;
+    }
+
+    f32x4 o[QF][DF];
+    float mrun[QF], lrun[QF];
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        mrun[a] = -1e30f;
+        lrun[a] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) o[a][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    int kend = p.Tk;
+    if (p.causal) {
+        const int qmax = min(p.Tq, (int)(blockIdx.x + 1) * 64 * QF);   // keys <= last query of the block
+        kend = min(kend, qmax);
+    }
+    const int ntiles = (kend + KT - 1) / KT;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * KT;
+        __syncthreads();       // previous tile fully consumed
+        // stage K and V tiles: KT*CH chunks each
+        for (int i = tid; i < KT * CH; i += 256) {
+            const int row = i / CH, ch = i - row * CH;
+            const int key = key0 + row;
+            f16x8 kv = zero8, vv = zero8;
+            if (key < p.Tk) {
+                kv = *reinterpret_cast<const f16x8*>(Kb + (int64_t)key * p.ldk + ch * 8);
+                vv = *reinterpret_cast<const f16x8*>(Vb + (int64_t)key * p.ldv + ch * 8);
+            }
+            *reinterpret_cast<f16x8*>(sk + kv_off<D>(row, ch)) = kv;
+            *reinterpret_cast<f16x8*>(sv + kv_off<D>(row, ch)) = vv;
+        }
+        __syncthreads();
+
+        // S^T[key][q] = sum_d K[key][d] Q[q][d]
+        f32x4 s[QF][KF];
+#pragma unroll
+        for (int a = 0; a < QF; ++a)
+#pragma unroll
+            for (int f = 0; f < KF; ++f) s[a][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DK; ++kk) {
+#pragma unroll
+            for (int f = 0; f < KF; ++f) {
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + kv_off<D>(f * 16 + fr, kk * 4 + fq));
+#pragma unroll
+                for (int a = 0; a < QF; ++a)
+                    s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf_[a][kk], s[a][f], 0, 0, 0);
+            }
+        }
+
+        // online softmax; lane element (a, f, r): key = key0 + f*16 + fq*4 + r, query = q0 + a*16 + fr
+        f16x8 pf[QF][PS];
+#pragma unroll
+        for (int a = 0; a < QF; ++a) {
+            const int q = q0 + a * 16 + fr;
+            float mx = -1e30f;
+#pragma unroll
+            for (int f = 0; f < KF; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + f * 16 + fq * 4 + r;
+                    float v = s[a][f][r] * p.scale_log2;
+                    if (key >= p.Tk || (p.causal && key > q)) v = -1e30f;
+                    s[a][f][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[a], mx);
+            const float alpha = exp2f(mrun[a] - mnew);
+            mrun[a] = mnew;
+            float sum = 0.f;
+#pragma unroll
+            for (int f = 0; f < KF; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(s[a][f][r] - mnew);
+                    sum += e;
+                    pf[a][f >> 1][(f & 1) * 4 + r] = (half_t)e;
+                }
+            lrun[a] = lrun[a] * alpha + sum;
+#pragma unroll
+            for (int d = 0; d < DF; ++d) o[a][d] *= alpha;
+        }
+
+        // O^T[d][q] += sum_key V[key][d] P[q][key]; V^T fragments by transposed LDS reads
+        const int trow = fq * 4 + (fr >> 2);                 // row inside a 16-key block supplied by this lane
+        const int tsub = (lane & 1) * 4;                     // element offset inside the 16-byte chunk
+#pragma unroll
+        for (int d = 0; d < DF; ++d) {
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+                const int ra = ps * 32 + trow, rb = ra + 16;
+                const int ch = d * 2 + ((lane & 3) >> 1);
+                const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(sv + kv_off<D>(ra, ch) + tsub));
+                const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(sv + kv_off<D>(rb, ch) + tsub));
+                union { struct { s16x4 lo, hi; } s; f16x8 v; } u;
+                u.s.lo = va;
+                u.s.hi = vb;
+#pragma unroll
+                for (int a = 0; a < QF; ++a)
+                    o[a][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pf[a][ps], o[a][d], 0, 0, 0);
+            }
+        }
+    }
+
+    // finalize: total row sum over the 4 lane groups, normalise, store 4 consecutive d per lane
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        float l = lrun[a];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int q = q0 + a * 16 + fr;
+        if (q >= p.Tq) continue;
+        half_t* orow = p.O + ((int64_t)b * p.Tq + q) * p.ldo + h * D;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) {
+            f16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[a][d][r] * inv);
+            *reinterpret_cast<f16x4*>(orow + d * 16 + fq * 4) = v;
+        }
+    }
+}
+
+template <int D, int QF, int KT>
+int launch_attn(fie_ctx* ctx, const AttnArgs& a, int B) {
+    const size_t lds = (size_t)2 * KT * D * sizeof(half_t);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QF, KT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((a.Tq + 64 * QF - 1) / (64 * QF)), (unsigned)a.H, (unsigned)B), block(256);
+    hipLaunchKernelGGL((attn_kernel<D, QF, KT>), grid, block, lds, ctx->stream, a);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+}  // namespace
+
+extern "C" int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V,
+                                 int64_t ldv, void* O, int64_t ldo, int B, int H, int Tq, int Tk, int D, float scale,
+                                 int causal) {
+    FIE_REQUIRE(ctx && Q && K && V && O, "fie_attention_f16: NULL argument");
+    FIE_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "fie_attention_f16: bad shape");
+    FIE_REQUIRE(D == 64 || D == 512, "fie_attention_f16: head dim %d not built (64, 512)", D);
+    FIE_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "fie_attention_f16: strides must be 16-byte aligned");
+    FIE_REQUIRE(ldq >= (int64_t)H * D && ldk >= (int64_t)H * D && ldv >= (int64_t)H * D && ldo >= (int64_t)H * D,
+                "fie_attention_f16: row stride smaller than H*D");
+    AttnArgs a;
+    a.Q = (const half_t*)Q; a.ldq = ldq; a.K = (const half_t*)K; a.ldk = ldk; a.V = (const half_t*)V; a.ldv = ldv;
+    a.O = (half_t*)O; a.ldo = ldo; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    if (D == 512) return launch_attn<512, 1, 32>(ctx, a, B);
+    const int64_t blocks128 = (int64_t)((Tq + 127) / 128) * H * B;
+    if (blocks128 >= ctx->num_cus * 2) return launch_attn<64, 2, 64>(ctx, a, B);
+    return launch_attn<64, 1, 64>(ctx, a, B);
+}

@@ -1,0 +1,45 @@
+// Internal helpers shared by the HIP translation units of libfie_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/fie.h"
+
+typedef _Float16 half_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct fie_ctx {
+    int device;
+    hipStream_t stream;
+    int num_cus;
+};
+
+void fie_set_error(const char* fmt, ...);
+
+#define FIE_REQUIRE(cond, ...)                         \
+    do {                                               \
+        if (!(cond)) {                                 \
+            fie_set_error(__VA_ARGS__);                \
+            return FIE_EINVAL;                         \
+        }                                              \
+    } while (0)
+
+#define FIE_LAUNCH_CHECK()                                                         \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            fie_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,           \
+                          hipGetErrorString(e__));                                 \
+            return FIE_EHIP;                                                       \
+        }                                                                          \
+    } while (0)
+
+static inline int64_t fie_roundup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+__device__ __forceinline__ float fie_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float fie_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float fie_qgelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }

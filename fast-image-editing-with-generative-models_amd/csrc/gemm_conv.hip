@@ -1,0 +1,341 @@
+// K1/K2: fp16 MFMA GEMM and 3x3 implicit-GEMM convolution for gfx950 (include/fie.h: fie_gemm_f16,
+// fie_conv3x3_nhwc_f16).
+//
+// One kernel template serves both: C[M,N] = epi(A[M,K] * W[N,K]^T) where the "A" operand is either a row-major
+// matrix (optionally the column concatenation of two matrices) or the on-the-fly im2col view of an NHWC tensor
+// (3x3 taps, stride 1/2, symmetric or VAE-style asymmetric padding, optional fused nearest-2x upsample).
+//
+// Tiling (CDNA4): 256 threads = 4 waves in a 2x2 grid, block tile BM x BN x 64, v_mfma_f32_16x16x32_f16.
+// The MFMA is issued "swapped": the weight fragment is the A operand and the activation fragment the B operand,
+// so each lane ends up with 4 CONSECUTIVE output channels of one output row -> 8-byte bias/residual loads and
+// 8-byte stores, and GEGLU value/gate pairs sit in one lane.
+// LDS: two buffers of (BM + BN) rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7) so that the
+// ds_read_b128 fragment reads of 16 different rows spread over the banks.  Global->LDS goes through registers
+// (the conv gather needs per-lane zero fill), issued one K-step ahead of the MFMAs that consume it.
+#include "fie_internal.h"
+
+namespace {
+
+constexpr int BK = 64;
+
+struct GemmArgs {
+    const half_t* A1; int64_t lda1; int K1;
+    const half_t* A2; int64_t lda2;
+    // conv view of A1
+    int H, W, Cin, OH, OW, stride, pt, pl, ups;
+    const half_t* Wt; int64_t ldw;
+    half_t* C; int64_t ldc;
+    int M, N, K;
+    const half_t* bias;
+    const half_t* rowbias; int64_t ld_rowbias; int rows_per_batch;
+    const half_t* res; int64_t ldr;
+    float scale; int act;
+    int nbm, nbn;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int RA = BM / 32, RW = BN / 32;       // 16-byte chunks per thread per K-step
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * (BM + BN) * BK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // XCD-aware tile order: consecutive ids on one XCD share the activation rows (n fastest)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / p.nbn) * BM;
+    const int n0 = (bid % p.nbn) * BN;
+
+    const int c8 = tid & 7;          // chunk column inside the K-step
+    const int r0 = tid >> 3;         // 0..31
+
+    // ---- per-thread A-row descriptors
+    int64_t a_base[RA];
+    int a_ih[RA], a_iw[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        a_ok[i] = m < p.M;
+        if (MODE == 1) {
+            const int hw = p.OH * p.OW;
+            const int b = m / hw, rem = m - b * hw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            a_ih[i] = oh * p.stride - p.pt;
+            a_iw[i] = ow * p.stride - p.pl;
+            a_base[i] = (int64_t)b * p.H * p.W * p.Cin;
+        } else {
+            a_base[i] = (int64_t)m;
+            a_ih[i] = a_iw[i] = 0;
+        }
+    }
+    int tap = 0, ci = c8 * 8;        // conv: position of this thread's chunk in (tap, channel) space
+    if (MODE == 1) {
+        while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+    }
+
+    f16x8 ra[RA], rw[RW];
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto load_tiles = [&](int kt) {
+        const int k = kt * BK + c8 * 8;
+        if (MODE == 1) {
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+            const int hlim = p.H << p.ups, wlim = p.W << p.ups;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int ih = a_ih[i] + ky, iw = a_iw[i] + kx;
+                const bool ok = a_ok[i] && tap < 9 && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+                const int64_t off = a_base[i] + ((int64_t)((ih >> p.ups) * p.W + (iw >> p.ups))) * p.Cin + ci;
+                ra[i] = ok ? *reinterpret_cast<const f16x8*>(p.A1 + off) : zero8;
+            }
+            ci += BK;
+            while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+        } else {
+            const bool k1 = k < p.K1;
+            const half_t* src = k1 ? p.A1 : p.A2;
+            const int64_t ld = k1 ? p.lda1 : p.lda2;
+            const int kk = k1 ? k : k - p.K1;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const bool ok = a_ok[i] && k < p.K;
+                ra[i] = ok ? *reinterpret_cast<const f16x8*>(src + a_base[i] * ld + kk) : zero8;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+            rw[i] = *reinterpret_cast<const f16x8*>(p.Wt + (int64_t)(n0 + r0 + 32 * i) * p.ldw + k);
+    };
+    auto store_tiles = [&](int buf) {
+        half_t* sa = smem + buf * (BM + BN) * BK;
+        half_t* sw = sa + BM * BK;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f16x8*>(sa + lds_off(r0 + 32 * i, c8)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) *reinterpret_cast<f16x8*>(sw + lds_off(r0 + 32 * i, c8)) = rw[i];
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        const half_t* sa = smem + buf * (BM + BN) * BK;
+        const half_t* sw = sa + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 fw[FN], fa[FM];
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+                fw[i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * WN + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+                fa[j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + j * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m = .. + fr][n = .. + fq*4 + (0..3)]
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = m0 + wm * WM + j * 16 + fr;
+        if (m >= p.M) continue;
+        const half_t* rb = nullptr;
+        if (p.rowbias) rb = p.rowbias + (int64_t)(m / p.rows_per_batch) * p.ld_rowbias;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int n = n0 + wn * WN + i * 16 + fq * 4;
+            if (n >= p.N) continue;
+            f32x4 v = acc[i][j];
+            if (p.bias) {
+                const f16x4 b = *reinterpret_cast<const f16x4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+            }
+            if (rb) {
+                const f16x4 b = *reinterpret_cast<const f16x4*>(rb + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+            }
+            if (p.act == FIE_ACT_GEGLU) {
+                f16x2 o;
+                o[0] = (half_t)(v[0] * fie_gelu(v[1]) * p.scale);
+                o[1] = (half_t)(v[2] * fie_gelu(v[3]) * p.scale);
+                *reinterpret_cast<f16x2*>(p.C + (int64_t)m * p.ldc + (n >> 1)) = o;
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = v[r];
+                if (p.act == FIE_ACT_SILU) x = fie_silu(x);
+                else if (p.act == FIE_ACT_GELU) x = fie_gelu(x);
+                else if (p.act == FIE_ACT_QUICK_GELU) x = fie_qgelu(x);
+                v[r] = x * p.scale;
+            }
+            if (p.res) {
+                const f16x4 b = *reinterpret_cast<const f16x4*>(p.res + (int64_t)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+            }
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+            *reinterpret_cast<f16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+        }
+    }
+}
+
+template <int MODE>
+int launch(fie_ctx* ctx, GemmArgs& a) {
+    auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+    const int64_t want = (int64_t)ctx->num_cus * 3 / 2;
+    int bm, bn;
+    if (blocks(128, 128) >= want) { bm = 128; bn = 128; }
+    else if (blocks(128, 64) >= want) { bm = 128; bn = 64; }
+    else { bm = 64; bn = 64; }
+    a.nbm = (a.M + bm - 1) / bm;
+    a.nbn = (a.N + bn - 1) / bn;
+    const dim3 grid((unsigned)(a.nbm * a.nbn)), block(256);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<128, 128, MODE>), grid, block, 0, ctx->stream, a);
+    else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<128, 64, MODE>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((gemm_kernel<64, 64, MODE>), grid, block, 0, ctx->stream, a);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+int check_epilogue(const char* who, int N, int64_t ldc, const void* res, int64_t ldr, int act) {
+    FIE_REQUIRE(act >= FIE_ACT_NONE && act <= FIE_ACT_GEGLU, "%s: unknown act %d", who, act);
+    FIE_REQUIRE(N % 4 == 0, "%s: N=%d must be a multiple of 4", who, N);
+    FIE_REQUIRE(ldc % 4 == 0 || act == FIE_ACT_GEGLU, "%s: ldc=%lld must be a multiple of 4", who, (long long)ldc);
+    FIE_REQUIRE(!res || ldr % 4 == 0, "%s: ldr=%lld must be a multiple of 4", who, (long long)ldr);
+    FIE_REQUIRE(!(res && act == FIE_ACT_GEGLU), "%s: GEGLU epilogue takes no residual", who);
+    return FIE_OK;
+}
+
+// ---- weight repack kernels
+__global__ void pack_rows_kernel(const half_t* src, int64_t ld_src, int N, int K, half_t* dst, int64_t ldw, int Npad,
+                                 int interleave2) {
+    const int64_t total = (int64_t)Npad * ldw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / ldw), k = (int)(i - (int64_t)n * ldw);
+        half_t v = (half_t)0.f;
+        if (n < N && k < K) {
+            const int sn = interleave2 ? ((n & 1) ? (N / 2 + (n >> 1)) : (n >> 1)) : n;
+            v = src[(int64_t)sn * ld_src + k];
+        }
+        dst[i] = v;
+    }
+}
+
+__global__ void pack_conv_kernel(const half_t* src, int Cout, int Cin, int cin_pad, half_t* dst, int64_t ldw, int Npad) {
+    const int64_t total = (int64_t)Npad * ldw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / ldw), k = (int)(i - (int64_t)n * ldw);
+        half_t v = (half_t)0.f;
+        const int tap = k / cin_pad, ci = k - tap * cin_pad;
+        if (n < Cout && tap < 9 && ci < Cin) v = src[((int64_t)n * Cin + ci) * 9 + tap];
+        dst[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fie_gemm_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2,
+                 const void* Wpacked, int64_t ldw, void* C, int64_t ldc, int M, int N, int K, const void* bias,
+                 const void* rowbias, int64_t ld_rowbias, int rows_per_batch, const void* residual, int64_t ldr,
+                 float scale, int act) {
+    FIE_REQUIRE(ctx && A1 && Wpacked && C, "fie_gemm_f16: NULL ctx/A1/W/C");
+    FIE_REQUIRE(M > 0 && N > 0 && K > 0, "fie_gemm_f16: bad shape M=%d N=%d K=%d", M, N, K);
+    FIE_REQUIRE(K % 8 == 0 && K1 % 8 == 0 && K1 > 0 && K1 <= K, "fie_gemm_f16: K=%d K1=%d must be multiples of 8", K, K1);
+    FIE_REQUIRE(lda1 % 8 == 0 && lda1 >= K1, "fie_gemm_f16: lda1=%lld invalid", (long long)lda1);
+    FIE_REQUIRE(K1 == K || (A2 && lda2 % 8 == 0 && lda2 >= K - K1), "fie_gemm_f16: A2/lda2 invalid for K1 < K");
+    FIE_REQUIRE(ldw % BK == 0 && ldw >= K, "fie_gemm_f16: ldw=%lld must be a multiple of 64 covering K", (long long)ldw);
+    FIE_REQUIRE(!rowbias || rows_per_batch > 0, "fie_gemm_f16: rowbias needs rows_per_batch");
+    if (int e = check_epilogue("fie_gemm_f16", N, ldc, residual, ldr, act)) return e;
+    GemmArgs a = {};
+    a.A1 = (const half_t*)A1; a.lda1 = lda1; a.K1 = K1; a.A2 = (const half_t*)A2; a.lda2 = lda2;
+    a.Wt = (const half_t*)Wpacked; a.ldw = ldw; a.C = (half_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
+    a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    a.res = (const half_t*)residual; a.ldr = ldr; a.scale = scale; a.act = act;
+    return launch<0>(ctx, a);
+}
+
+int fie_conv3x3_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, int upsample2x, int stride,
+                         int pad_mode, const void* Wpacked, int64_t ldw, void* Y, int64_t ldc, int Cout,
+                         const void* bias, const void* rowbias, int64_t ld_rowbias, const void* residual,
+                         int64_t ldr, float scale, int act) {
+    FIE_REQUIRE(ctx && X && Wpacked && Y, "fie_conv3x3_nhwc_f16: NULL ctx/X/W/Y");
+    FIE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "fie_conv3x3_nhwc_f16: bad shape");
+    FIE_REQUIRE(Cin % 8 == 0, "fie_conv3x3_nhwc_f16: Cin=%d must be a multiple of 8 (pad the tensor)", Cin);
+    FIE_REQUIRE(stride == 1 || stride == 2, "fie_conv3x3_nhwc_f16: stride %d", stride);
+    FIE_REQUIRE(pad_mode == 0 || pad_mode == 1, "fie_conv3x3_nhwc_f16: pad_mode %d", pad_mode);
+    FIE_REQUIRE(act != FIE_ACT_GEGLU, "fie_conv3x3_nhwc_f16: GEGLU not supported");
+    const int K = 9 * Cin;
+    FIE_REQUIRE(ldw % BK == 0 && ldw >= K, "fie_conv3x3_nhwc_f16: ldw=%lld must be a multiple of 64 covering 9*Cin",
+                (long long)ldw);
+    if (int e = check_epilogue("fie_conv3x3_nhwc_f16", Cout, ldc, residual, ldr, act)) return e;
+    const int ups = upsample2x ? 1 : 0;
+    const int Hin = H << ups, Win = W << ups;
+    const int pads = pad_mode == 0 ? 2 : 1;
+    const int OH = (Hin + pads - 3) / stride + 1, OW = (Win + pads - 3) / stride + 1;
+    FIE_REQUIRE((int64_t)B * OH * OW < (1ll << 31), "fie_conv3x3_nhwc_f16: too many output pixels");
+    GemmArgs a = {};
+    a.A1 = (const half_t*)X; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.stride = stride;
+    a.pt = a.pl = pad_mode == 0 ? 1 : 0; a.ups = ups;
+    a.Wt = (const half_t*)Wpacked; a.ldw = ldw; a.C = (half_t*)Y; a.ldc = ldc;
+    a.M = B * OH * OW; a.N = Cout; a.K = K; a.K1 = K;
+    a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
+    a.rows_per_batch = OH * OW; a.res = (const half_t*)residual; a.ldr = ldr; a.scale = scale; a.act = act;
+    return launch<1>(ctx, a);
+}
+
+int fie_pack_rows_f16(fie_ctx* ctx, const void* src, int64_t ld_src, int N, int K, void* dst, int64_t ldw,
+                      int Npad, int interleave2) {
+    FIE_REQUIRE(ctx && src && dst, "fie_pack_rows_f16: NULL argument");
+    FIE_REQUIRE(N > 0 && K > 0 && Npad >= N && ldw >= K, "fie_pack_rows_f16: bad shape");
+    FIE_REQUIRE(!interleave2 || N % 2 == 0, "fie_pack_rows_f16: interleave2 needs even N");
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const half_t*)src, ld_src, N, K,
+                       (half_t*)dst, ldw, Npad, interleave2);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+int fie_pack_conv3x3_f16(fie_ctx* ctx, const void* src_oihw, int Cout, int Cin, int cin_pad, void* dst, int64_t ldw,
+                         int Npad) {
+    FIE_REQUIRE(ctx && src_oihw && dst, "fie_pack_conv3x3_f16: NULL argument");
+    FIE_REQUIRE(cin_pad >= Cin && cin_pad % 8 == 0 && ldw >= 9 * cin_pad && Npad >= Cout, "fie_pack_conv3x3_f16: bad shape");
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const half_t*)src_oihw, Cout, Cin,
+                       cin_pad, (half_t*)dst, ldw, Npad);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+}  // extern "C"

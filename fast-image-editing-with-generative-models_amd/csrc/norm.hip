@@ -1,0 +1,254 @@
+// K5 GroupNorm(+SiLU) and K6 LayerNorm for gfx950 -- HBM-bound, 16-byte vector accesses, fp32 statistics.
+// (include/fie.h: fie_groupnorm_nhwc_f16, fie_layernorm_f16)
+//
+// GroupNorm over NHWC [B, rows, C] with the channel dim optionally split over two source tensors (the UNet up
+// blocks' concat is never materialised before its GroupNorm).  Three launches:
+//   1. partial sums   grid (chunks, B, csplit): each thread owns ONE 8-channel column chunk and walks rows,
+//                     block-reduces to per-group (sum, sumsq) partials -> workspace [B][chunks][G][2] (deterministic)
+//   2. finalize       one thread per (b, g): reduce chunk partials -> (mean, rstd)
+//   3. apply          same thread->column mapping; y = x * a_c + b_c with a, b folded from gamma/beta/mean/rstd, SiLU
+#include "fie_internal.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_CHUNKS = 1024;
+
+struct GnArgs {
+    const half_t* X1; int C1;
+    const half_t* X2; int C2;
+    half_t* Y;
+    int C, G, cg;
+    int64_t rows;            // per image
+    int rows_per_chunk, nchunks;
+    int ncol;                // 8-channel column chunks handled per block (<= 256)
+    int rpp;                 // rows per pass = 256 / ncol
+    const half_t* gamma; const half_t* beta;
+    float eps; int silu;
+    float* partial;          // [B][nchunks][G][2]
+    float* stats;            // [B][G][2] mean, rstd
+};
+
+__device__ __forceinline__ f16x8 gn_load(const GnArgs& p, int64_t row_global, int c0) {
+    if (c0 < p.C1) return *reinterpret_cast<const f16x8*>(p.X1 + row_global * p.C1 + c0);
+    return *reinterpret_cast<const f16x8*>(p.X2 + row_global * p.C2 + (c0 - p.C1));
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(GnArgs p) {
+    __shared__ float red[GN_THREADS * 16];
+    const int tid = threadIdx.x;
+    const int col = tid % p.ncol, rsub = tid / p.ncol;
+    const int b = blockIdx.y;
+    const int c0 = (blockIdx.z * p.ncol + col) * 8;
+    const bool active = rsub < p.rpp && c0 < p.C;
+    float s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+    if (active) {
+        const int64_t r_begin = (int64_t)blockIdx.x * p.rows_per_chunk;
+        const int64_t r_end = min(r_begin + p.rows_per_chunk, p.rows);
+        for (int64_t r = r_begin + rsub; r < r_end; r += p.rpp) {
+            const f16x8 v = gn_load(p, (int64_t)b * p.rows + r, c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = (float)v[j];
+                s[j] += x;
+                ss[j] += x * x;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[tid * 16 + j] = s[j];
+        red[tid * 16 + 8 + j] = ss[j];
+    }
+    __syncthreads();
+    // groups covered by this block's channel range: [cbase, cbase + ncol*8)
+    const int cbase = blockIdx.z * p.ncol * 8;
+    const int cend = min(cbase + p.ncol * 8, p.C);
+    const int g_first = cbase / p.cg, g_last = (cend - 1) / p.cg;
+    for (int g = g_first + tid; g <= g_last; g += GN_THREADS) {
+        float a = 0.f, q = 0.f;
+        const int ch_lo = max(g * p.cg, cbase), ch_hi = min((g + 1) * p.cg, cend);
+        for (int ch = ch_lo; ch < ch_hi; ++ch) {
+            const int lc = (ch - cbase) >> 3, j = (ch - cbase) & 7;
+            for (int rs = 0; rs < p.rpp; ++rs) {
+                a += red[(rs * p.ncol + lc) * 16 + j];
+                q += red[(rs * p.ncol + lc) * 16 + 8 + j];
+            }
+        }
+        float* dst = p.partial + (((int64_t)b * p.nchunks + blockIdx.x) * p.G + g) * 2;
+        // a group never straddles two column splits (checked on the host), so plain stores suffice
+        dst[0] = a;
+        dst[1] = q;
+    }
+}
+
+__global__ void gn_finalize_kernel(GnArgs p, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * p.G) return;
+    const int b = i / p.G, g = i - b * p.G;
+    double a = 0.0, q = 0.0;
+    for (int c = 0; c < p.nchunks; ++c) {
+        const float* src = p.partial + (((int64_t)b * p.nchunks + c) * p.G + g) * 2;
+        a += (double)src[0];
+        q += (double)src[1];
+    }
+    const double n = (double)p.rows * p.cg;
+    const double mean = a / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    p.stats[i * 2] = (float)mean;
+    p.stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
+    const int tid = threadIdx.x;
+    const int col = tid % p.ncol, rsub = tid / p.ncol;
+    const int b = blockIdx.y;
+    const int c0 = (blockIdx.z * p.ncol + col) * 8;
+    if (!(rsub < p.rpp && c0 < p.C)) return;
+    float sc[8], sh[8];
+    const f16x8 gm = *reinterpret_cast<const f16x8*>(p.gamma + c0);
+    const f16x8 bt = *reinterpret_cast<const f16x8*>(p.beta + c0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (c0 + j) / p.cg;
+        const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
+        sc[j] = rstd * (float)gm[j];
+        sh[j] = (float)bt[j] - mean * sc[j];
+    }
+    const int64_t r_begin = (int64_t)blockIdx.x * p.rows_per_chunk;
+    const int64_t r_end = min(r_begin + p.rows_per_chunk, p.rows);
+    for (int64_t r = r_begin + rsub; r < r_end; r += p.rpp) {
+        const int64_t rg = (int64_t)b * p.rows + r;
+        const f16x8 v = gn_load(p, rg, c0);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y = (float)v[j] * sc[j] + sh[j];
+            if (p.silu) y = fie_silu(y);
+            o[j] = (half_t)y;
+        }
+        *reinterpret_cast<f16x8*>(p.Y + rg * p.C + c0) = o;
+    }
+}
+
+// ---- LayerNorm: one wave per row, row kept in registers (C <= 4096)
+constexpr int LN_MAXV = 8;   // 8 chunks x 8 values per lane
+
+__global__ __launch_bounds__(256) void ln_kernel(const half_t* X, int64_t ldx, half_t* Y, int64_t ldy, int64_t rows,
+                                                 int C, const half_t* gamma, const half_t* beta, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = C >> 3;
+    f16x8 v[LN_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            v[i] = *reinterpret_cast<const f16x8*>(X + row * ldx + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = (float)v[i][j] - mean;
+                var += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = rsqrtf(var / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            const f16x8 g = *reinterpret_cast<const f16x8*>(gamma + ch * 8);
+            const f16x8 bb = *reinterpret_cast<const f16x8*>(beta + ch * 8);
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[i][j] - mean) * rstd * (float)g[j] + (float)bb[j]);
+            *reinterpret_cast<f16x8*>(Y + row * ldy + ch * 8) = o;
+        }
+    }
+}
+
+int gn_plan(GnArgs& p, int C, int G, int64_t rows, int* csplit) {
+    const int nc8 = C / 8;
+    int split = (nc8 + GN_THREADS - 1) / GN_THREADS;
+    while (split <= nc8 && (nc8 % split != 0 || ((nc8 / split) * 8) % (C / G) != 0)) ++split;
+    if (split > nc8) return -1;
+    p.ncol = nc8 / split;
+    p.rpp = GN_THREADS / p.ncol;
+    *csplit = split;
+    int64_t rpc = rows / 512;
+    if (rpc < 16) rpc = 16;
+    rpc = fie_roundup(rpc, p.rpp);
+    int64_t nch = (rows + rpc - 1) / rpc;
+    if (nch > GN_MAX_CHUNKS) {
+        rpc = fie_roundup((rows + GN_MAX_CHUNKS - 1) / GN_MAX_CHUNKS, p.rpp);
+        nch = (rows + rpc - 1) / rpc;
+    }
+    p.rows_per_chunk = (int)rpc;
+    p.nchunks = (int)nch;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t fie_groupnorm_workspace_bytes(int B, int64_t rows_per_image, int groups) {
+    (void)rows_per_image;
+    return ((int64_t)B * GN_MAX_CHUNKS * groups * 2 + (int64_t)B * groups * 2) * (int64_t)sizeof(float);
+}
+
+int fie_groupnorm_nhwc_f16(fie_ctx* ctx, const void* X1, int C1, const void* X2, int C2, void* Y, int B,
+                           int64_t rows_per_image, int groups, const void* gamma, const void* beta, float eps,
+                           int silu, void* workspace) {
+    FIE_REQUIRE(ctx && X1 && Y && gamma && beta && workspace, "fie_groupnorm_nhwc_f16: NULL argument");
+    FIE_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0 && (C2 == 0 || X2), "fie_groupnorm_nhwc_f16: C1=%d C2=%d invalid", C1, C2);
+    const int C = C1 + C2;
+    FIE_REQUIRE(B > 0 && rows_per_image > 0 && groups > 0 && C % groups == 0, "fie_groupnorm_nhwc_f16: bad shape C=%d G=%d", C, groups);
+    GnArgs p = {};
+    p.X1 = (const half_t*)X1; p.C1 = C1; p.X2 = (const half_t*)X2; p.C2 = C2; p.Y = (half_t*)Y;
+    p.C = C; p.G = groups; p.cg = C / groups; p.rows = rows_per_image;
+    p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.eps = eps; p.silu = silu;
+    int csplit = 1;
+    FIE_REQUIRE(gn_plan(p, C, groups, rows_per_image, &csplit) == 0,
+                "fie_groupnorm_nhwc_f16: cannot split C=%d (groups=%d) into aligned column blocks", C, groups);
+    p.partial = (float*)workspace;
+    p.stats = p.partial + (int64_t)B * GN_MAX_CHUNKS * groups * 2;
+    const dim3 grid((unsigned)p.nchunks, (unsigned)B, (unsigned)csplit);
+    hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(GN_THREADS), 0, ctx->stream, p);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 255) / 256), dim3(256), 0, ctx->stream, p, B);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), 0, ctx->stream, p);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+int fie_layernorm_f16(fie_ctx* ctx, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int C,
+                      const void* gamma, const void* beta, float eps) {
+    FIE_REQUIRE(ctx && X && Y && gamma && beta, "fie_layernorm_f16: NULL argument");
+    FIE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "fie_layernorm_f16: C=%d unsupported", C);
+    FIE_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "fie_layernorm_f16: bad strides");
+    hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const half_t*)X, ldx,
+                       (half_t*)Y, ldy, rows, C, (const half_t*)gamma, (const half_t*)beta, eps);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+}  // extern "C"

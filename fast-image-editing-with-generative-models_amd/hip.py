@@ -1,0 +1,261 @@
+"""ctypes binding of ``csrc/libfie_hip.so`` (C ABI: include/fie.h) + thin tensor-level wrappers.
+
+PyTorch-ROCm is plumbing here: it owns device memory (``tensor.data_ptr()``) and the current stream; every
+multiply-add of the hot path runs in the hand-written HIP kernels behind these wrappers.  There is NO fallback:
+if the library is missing or the device is not gfx950 the first call raises.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libfie_hip.so")
+
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU, ACT_GEGLU = 0, 1, 2, 3, 4
+
+_c = ctypes
+_P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
+
+# name -> argtypes, mirrors include/fie.h one to one (tests/test_cabi_cpu.py checks every symbol is exported)
+SIGNATURES = {
+    "fie_version": [],
+    "fie_ctx_create": [_I, _P, _c.POINTER(_P)],
+    "fie_ctx_set_stream": [_P, _P],
+    "fie_ctx_destroy": [_P],
+    "fie_gemm_f16": [_P, _P, _L, _I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _P, _L, _F, _I],
+    "fie_conv3x3_nhwc_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P, _P, _L, _P, _L, _F, _I],
+    "fie_attention_f16": [_P, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I],
+    "fie_groupnorm_workspace_bytes": [_I, _L, _I],
+    "fie_groupnorm_nhwc_f16": [_P, _P, _I, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P],
+    "fie_layernorm_f16": [_P, _P, _L, _P, _L, _L, _I, _P, _P, _F],
+    "fie_sinusoid_f16": [_P, _P, _I, _I, _I, _P, _L, _I],
+    "fie_clip_embed_f16": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "fie_pixels_in_u8_f16": [_P, _P, _I, _I, _I, _P, _I],
+    "fie_pixels_out_f16_u8": [_P, _P, _L, _I, _I, _P],
+    "fie_latent_prep": [_P, _P, _P, _P, _L, _F, _F, _F, _P, _P, _I],
+    "fie_lcm_step": [_P, _P, _L, _I, _F, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _I, _F, _P],
+    "fie_pack_rows_f16": [_P, _P, _L, _I, _I, _P, _L, _I, _I],
+    "fie_pack_conv3x3_f16": [_P, _P, _I, _I, _I, _P, _L, _I],
+    "fie_canny_rgb_u8": [_P, _I, _I, _I, _I, _P],
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", _CSRC, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", _CSRC, "-j4"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libfie_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no non-HIP fallback for the hot path)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = args
+            fn.restype = _L if name == "fie_groupnorm_workspace_bytes" else _I
+        _lib.fie_last_error.restype = ctypes.c_char_p
+        _lib.fie_last_error.argtypes = []
+    return _lib
+
+
+class FieError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise FieError(f"libfie_hip error {rc}: {lib().fie_last_error().decode()}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class Context:
+    """One fie_ctx per (process, device); launches go to torch's current stream on that device."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the fie_amd hot path has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        h = _P()
+        _chk(lib().fie_ctx_create(device, None, ctypes.byref(h)))
+        self.h = h
+        self._stream = None
+        self._gn_ws = None
+
+    def sync_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._stream:
+            _chk(lib().fie_ctx_set_stream(self.h, s))
+            self._stream = s
+
+    def close(self):
+        if self.h:
+            lib().fie_ctx_destroy(self.h)
+            self.h = None
+
+    # ------------------------------------------------------------------ weight packing
+    def pack_linear(self, w, geglu=False):
+        """[N, K] f16 -> packed [Npad][Kpad] (zero padded); geglu interleaves (value, gate) rows."""
+        self.sync_stream()
+        w = w.to(self.device, torch.float16).contiguous()
+        n, k = w.shape
+        npad, kpad = (n + 127) // 128 * 128, (k + 63) // 64 * 64
+        out = torch.empty((npad, kpad), device=self.device, dtype=torch.float16)
+        _chk(lib().fie_pack_rows_f16(self.h, _p(w), k, n, k, _p(out), kpad, npad, int(geglu)))
+        return out
+
+    def pack_conv3x3(self, w, cin_pad=None):
+        """OIHW f16 -> packed [Npad][Kpad], k = (ky*3+kx)*cin_pad + ci."""
+        self.sync_stream()
+        w = w.to(self.device, torch.float16).contiguous()
+        co, ci = w.shape[:2]
+        cin_pad = cin_pad or (ci + 7) // 8 * 8
+        npad, kpad = (co + 127) // 128 * 128, (9 * cin_pad + 63) // 64 * 64
+        out = torch.empty((npad, kpad), device=self.device, dtype=torch.float16)
+        _chk(lib().fie_pack_conv3x3_f16(self.h, _p(w), co, ci, cin_pad, _p(out), kpad, npad))
+        return out
+
+    # ------------------------------------------------------------------ ops
+    def gemm(self, a, wp, n, out=None, a2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None, scale=1.0,
+             act=ACT_NONE, k=None):
+        """a: [M, K1] (last-dim contiguous, row stride free), optional a2: [M, K2]; wp packed weight; n logical N."""
+        self.sync_stream()
+        m, k1 = a.shape
+        ktot = k1 + (a2.shape[1] if a2 is not None else 0)
+        if k is not None:
+            assert k == ktot
+        nout = n // 2 if act == ACT_GEGLU else n
+        if out is None:
+            out = torch.empty((m, nout), device=a.device, dtype=torch.float16)
+        assert a.stride(1) == 1 and out.stride(1) == 1
+        _chk(lib().fie_gemm_f16(self.h, _p(a), a.stride(0), k1, _p(a2), a2.stride(0) if a2 is not None else 0,
+                                _p(wp), wp.stride(0), _p(out), out.stride(0), m, n, ktot, _p(bias), _p(rowbias),
+                                rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
+                                residual.stride(0) if residual is not None else 0, float(scale), act))
+        return out
+
+    def conv3x3(self, x, wp, cout, out=None, stride=1, pad_mode=0, upsample=False, bias=None, rowbias=None,
+                residual=None, scale=1.0, act=ACT_NONE, ldc=None):
+        """x: [B, H, W, Cin] f16 contiguous NHWC -> [B, OH, OW, ldc]."""
+        self.sync_stream()
+        b, h, w, cin = x.shape
+        assert x.is_contiguous()
+        hin, win = (h * 2, w * 2) if upsample else (h, w)
+        pads = 2 if pad_mode == 0 else 1
+        oh, ow = (hin + pads - 3) // stride + 1, (win + pads - 3) // stride + 1
+        ldc = ldc or cout
+        if out is None:
+            out = (torch.zeros if ldc != cout else torch.empty)((b, oh, ow, ldc), device=x.device, dtype=torch.float16)
+        _chk(lib().fie_conv3x3_nhwc_f16(self.h, _p(x), b, h, w, cin, int(upsample), stride, pad_mode, _p(wp),
+                                        wp.stride(0), _p(out), out.stride(2), cout, _p(bias), _p(rowbias),
+                                        rowbias.stride(0) if rowbias is not None else 0, _p(residual),
+                                        residual.stride(2) if residual is not None else 0, float(scale), act))
+        return out
+
+    def attention(self, q, k, v, heads, head_dim, tq, tk, batch, out=None, causal=False, scale=None):
+        """q: [B*Tq, >=H*D] view (row stride free); k, v: [B*Tk, ...]; returns [B*Tq, H*D]."""
+        self.sync_stream()
+        if out is None:
+            out = torch.empty((batch * tq, heads * head_dim), device=q.device, dtype=torch.float16)
+        scale = scale if scale is not None else head_dim ** -0.5
+        _chk(lib().fie_attention_f16(self.h, _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
+                                     out.stride(0), batch, heads, tq, tk, head_dim, float(scale), int(causal)))
+        return out
+
+    def groupnorm(self, x1, gamma, beta, groups, eps, silu, x2=None, out=None):
+        """x1: [B, rows, C1] (+ x2: [B, rows, C2]) NHWC-flattened, contiguous -> [B, rows, C1+C2]."""
+        self.sync_stream()
+        b, rows, c1 = x1.shape[0], x1[0].numel() // x1.shape[-1], x1.shape[-1]
+        c2 = x2.shape[-1] if x2 is not None else 0
+        assert x1.is_contiguous() and (x2 is None or x2.is_contiguous())
+        if out is None:
+            out = torch.empty(x1.shape[:-1] + (c1 + c2,), device=x1.device, dtype=torch.float16)
+        need = lib().fie_groupnorm_workspace_bytes(b, rows, groups)
+        if self._gn_ws is None or self._gn_ws.numel() < need:
+            self._gn_ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+        _chk(lib().fie_groupnorm_nhwc_f16(self.h, _p(x1), c1, _p(x2), c2, _p(out), b, rows, groups, _p(gamma),
+                                          _p(beta), float(eps), int(silu), _p(self._gn_ws)))
+        return out
+
+    def layernorm(self, x, gamma, beta, eps=1e-5, out=None):
+        self.sync_stream()
+        rows, c = x.shape
+        if out is None:
+            out = torch.empty((rows, c), device=x.device, dtype=torch.float16)
+        _chk(lib().fie_layernorm_f16(self.h, _p(x), x.stride(0), _p(out), out.stride(0), rows, c, _p(gamma), _p(beta),
+                                     float(eps)))
+        return out
+
+    def sinusoid(self, vals, dim, out, col0=0):
+        """vals: f32 [B, nvals] on device; writes [cos|sin] blocks of width dim into out[:, col0:]."""
+        self.sync_stream()
+        b, nv = vals.shape
+        _chk(lib().fie_sinusoid_f16(self.h, _p(vals), b, nv, dim, _p(out), out.stride(0), col0))
+        return out
+
+    def clip_embed(self, ids, tok, pos):
+        self.sync_stream()
+        b, t = ids.shape
+        c = tok.shape[1]
+        out = torch.empty((b * t, c), device=tok.device, dtype=torch.float16)
+        _chk(lib().fie_clip_embed_f16(self.h, _p(ids), b, t, c, _p(tok), _p(pos), _p(out)))
+        return out
+
+    def pixels_in(self, u8_hwc, normalize, copies=1):
+        self.sync_stream()
+        h, w, _ = u8_hwc.shape
+        out = torch.empty((copies, h, w, 8), device=u8_hwc.device, dtype=torch.float16)
+        _chk(lib().fie_pixels_in_u8_f16(self.h, _p(u8_hwc), h, w, int(normalize), _p(out), copies))
+        return out
+
+    def pixels_out(self, x_nhwc):
+        self.sync_stream()
+        _, h, w, ld = x_nhwc.shape
+        out = torch.empty((h, w, 3), device=x_nhwc.device, dtype=torch.uint8)
+        _chk(lib().fie_pixels_out_f16_u8(self.h, _p(x_nhwc), ld, h, w, _p(out)))
+        return out
+
+    def latent_prep(self, moments, eps_post, noise, hw, sf, sqrt_ab, sqrt_1mab, latents, model_in):
+        self.sync_stream()
+        _chk(lib().fie_latent_prep(self.h, _p(moments), _p(eps_post), _p(noise), hw, float(sf), float(sqrt_ab),
+                                   float(sqrt_1mab), _p(latents), _p(model_in), model_in.shape[0]))
+
+    def lcm_step(self, eps, nb, guidance, latents, noise, hw, sab_t, s1mab_t, c_skip, c_out, sab_p, s1mab_p, model_in,
+                 inv_sf, decode_in):
+        self.sync_stream()
+        _chk(lib().fie_lcm_step(self.h, _p(eps), eps.shape[-1], nb, float(guidance), _p(latents), _p(noise), hw,
+                                float(sab_t), float(s1mab_t), float(c_skip), float(c_out), float(sab_p),
+                                float(s1mab_p), _p(model_in), model_in.shape[0] if model_in is not None else 0,
+                                float(inv_sf), _p(decode_in)))
+
+
+def canny_rgb(rgb_u8, low=100, high=200):
+    """Host Canny through the C ABI (numpy uint8 HxWx3 in and out)."""
+    import numpy as np
+    a = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
+    out = np.empty_like(a)
+    _chk(lib().fie_canny_rgb_u8(a.ctypes.data, a.shape[0], a.shape[1], int(low), int(high), out.ctypes.data))
+    return out
+
+
+_ctx = {}
+
+
+def context(device=0):
+    if device not in _ctx:
+        _ctx[device] = Context(device)
+    return _ctx[device]

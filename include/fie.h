@@ -1,0 +1,141 @@
+/*
+ * fie.h -- C ABI of the MI355X (gfx950) hot-path library `libfie_hip.so`.
+ *
+ * The reference (/root/reference) is pure Python and has NO FFI of its own: every multiply-add of its hot call
+ * `self.pipe(...)` (src/pipeline.py:261-272) runs inside diffusers/transformers/torch/OpenCV.  This header is
+ * therefore the boundary a maintainer would bind from Python (ctypes stub in INTEGRATION.md) to replace those
+ * upstream internals.  Each entry names the reference call site / upstream module it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns 0 on success or a
+ *     negative FIE_E* code; `fie_last_error()` returns a thread-local message for the last failure.
+ *   - All device pointers are owned by the caller (PyTorch-ROCm allocations: tensor.data_ptr()).  The library never
+ *     allocates device memory; kernels that need scratch take a caller-provided workspace.
+ *   - Every launch is asynchronous on the ctx's stream and never synchronises (hipGraph-capturable).
+ *   - fp16 storage ("f16" = IEEE binary16), fp32 accumulation.  Activations are NHWC; a tensor with C channels
+ *     has C % 8 == 0 (3/4-channel images and latents are stored zero-padded to 8 channels unless stated).
+ *   - One ctx per (thread, device); a ctx is not thread-safe; distinct ctxs are independent.
+ */
+#ifndef FIE_H_
+#define FIE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIE_OK 0
+#define FIE_EINVAL (-1)   /* bad argument / unsupported shape */
+#define FIE_EHIP (-2)     /* HIP runtime error */
+#define FIE_ENODEV (-3)   /* no gfx950 device */
+
+/* epilogue activations (applied to acc + bias [+ rowbias]) */
+#define FIE_ACT_NONE 0
+#define FIE_ACT_SILU 1
+#define FIE_ACT_GELU 2        /* exact erf GELU */
+#define FIE_ACT_QUICK_GELU 3  /* x * sigmoid(1.702 x), CLIP-L */
+#define FIE_ACT_GEGLU 4       /* weight rows interleaved (value, gate): out[j] = v_j * gelu(g_j); N counts both */
+
+typedef struct fie_ctx fie_ctx;
+
+int fie_version(void);
+const char* fie_last_error(void);
+/* stream: hipStream_t (0 = default stream).  Replaces: nothing in the reference (torch owns streams there). */
+int fie_ctx_create(int device, void* stream, fie_ctx** out);
+int fie_ctx_set_stream(fie_ctx* ctx, void* stream);
+int fie_ctx_destroy(fie_ctx* ctx);
+
+/* ---- K2 GEMM (Linear / 1x1 conv).  Replaces torch.nn.Linear / 1x1 Conv2d dispatched by upstream
+ * diffusers models/attention.py, transformer_2d.py, resnet.py (conv_shortcut), controlnet.py (zero convs),
+ * embeddings.py (TimestepEmbedding), transformers modeling_clip.py -- all reached from src/pipeline.py:261.
+ *   C[m, n] = epi( sum_k A[m, k] * W[n, k] ),  A = [A1 | A2] column-concatenated (A2 may be NULL; K1 = K then)
+ *   epi(v) = act(v + bias[n] + rowbias[m / rows_per_batch, n]) * scale + residual[m, n]
+ * W is the PACKED weight: [Npad][Kpad] f16, Kpad = roundup(K, 64), Npad = roundup(N, 128), zero filled (see
+ * fie_pack_rows).  lda*, ldc, ldr in elements, multiples of 8 (ldc, ldr: multiples of 4).  K1 % 8 == 0, K % 8 == 0.
+ * For FIE_ACT_GEGLU the output has N/2 columns. */
+int fie_gemm_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2,
+                 const void* Wpacked, int64_t ldw, void* C, int64_t ldc, int M, int N, int K,
+                 const void* bias, const void* rowbias, int64_t ld_rowbias, int rows_per_batch,
+                 const void* residual, int64_t ldr, float scale, int act);
+
+/* ---- K1 3x3 convolution, NHWC, implicit GEMM on fp16 MFMA.  Replaces torch Conv2d(3x3) dispatched by upstream
+ * resnet.py / downsampling.py / upsampling.py / vae.py / controlnet.py conditioning embedding.
+ *   X: [B, H, W, Cin] f16 (Cin % 8 == 0).  If upsample2x != 0 the conv sees nearest-2x upsampled X (never stored).
+ *   pad_mode 0: symmetric padding 1.  pad_mode 1: pad (right, bottom) only -- the VAE encoder's F.pad(0,1,0,1) + pad 0.
+ *   Y: [B, OH, OW, ldc] with OH = (Hin + pads - 3)/stride + 1.  Wpacked: [Npad][Kpad], k = (ky*3 + kx)*Cin + ci.
+ *   epilogue as fie_gemm_f16 with rows_per_batch = OH*OW (rowbias = per-image time-embedding projection). */
+int fie_conv3x3_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, int upsample2x, int stride,
+                         int pad_mode, const void* Wpacked, int64_t ldw, void* Y, int64_t ldc, int Cout,
+                         const void* bias, const void* rowbias, int64_t ld_rowbias,
+                         const void* residual, int64_t ldr, float scale, int act);
+
+/* ---- K3/K3v/K4 + CLIP attention: softmax(scale * Q K^T [+ causal mask]) V, online softmax, one kernel family.
+ * Replaces F.scaled_dot_product_attention reached via upstream attention_processor.py (UNet/ControlNet attn1/attn2,
+ * VAE mid-block attention) and modeling_clip.py self-attention.
+ *   element (b, t, h, d) of Q lives at Q[(b*Tq + t)*ldq + h*D + d]; K/V likewise with Tk, ldk, ldv; O with ldo.
+ *   D in {64, 512}.  kv_batch_stride_zero != 0 broadcasts one K/V over the batch. */
+int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V,
+                      int64_t ldv, void* O, int64_t ldo, int B, int H, int Tq, int Tk, int D, float scale,
+                      int causal);
+
+/* ---- K5 GroupNorm (+SiLU), NHWC, fp32 statistics.  Replaces torch GroupNorm + SiLU in resnet.py /
+ * transformer_2d.py / vae.py.  Input is the channel concatenation [X1 (C1) | X2 (C2)] (X2 may be NULL): this
+ * is how the UNet up blocks' torch.cat([x, skip]) is consumed without materialising the concat.
+ *   workspace: fie_groupnorm_workspace_bytes(B, rows, G) bytes of device scratch. */
+int64_t fie_groupnorm_workspace_bytes(int B, int64_t rows_per_image, int groups);
+int fie_groupnorm_nhwc_f16(fie_ctx* ctx, const void* X1, int C1, const void* X2, int C2, void* Y, int B,
+                           int64_t rows_per_image, int groups, const void* gamma, const void* beta, float eps,
+                           int silu, void* workspace);
+
+/* ---- K6 LayerNorm over the last dim (affine).  Replaces torch LayerNorm in attention.py / modeling_clip.py. */
+int fie_layernorm_f16(fie_ctx* ctx, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int C,
+                      const void* gamma, const void* beta, float eps);
+
+/* ---- K7 sinusoidal embeddings.  Replaces embeddings.py::get_timestep_embedding (flip_sin_to_cos, shift 0).
+ *   out[b, i*dim .. (i+1)*dim) = [cos(v f), sin(v f)] for each of the `nvals` scalars v of row b; out row
+ *   stride ld_out, column offset col0 (so the 6 add_time_ids land behind the pooled text embedding). */
+int fie_sinusoid_f16(fie_ctx* ctx, const float* vals, int B, int nvals, int dim, void* out, int64_t ld_out,
+                     int col0);
+
+/* ---- K12 token + position embedding gather (CLIPTextEmbeddings). ids: int32 [B*T] on device. */
+int fie_clip_embed_f16(fie_ctx* ctx, const int32_t* ids, int B, int T, int C, const void* tok_table,
+                       const void* pos_table, void* out);
+
+/* ---- K10 pixels.  Replaces image_processor.py::VaeImageProcessor.preprocess / postprocess.
+ *   in : u8 HWC (3 ch) -> f16 NHWC padded to 8 ch; normalize != 0: x/255*2-1, else x/255; `copies` batch copies.
+ *   out: f16 NHWC (ld_in channels, first 3 used) -> u8 HWC: round(clamp(x/2+0.5, 0, 1) * 255). */
+int fie_pixels_in_u8_f16(fie_ctx* ctx, const uint8_t* src, int H, int W, int normalize, void* dst, int copies);
+int fie_pixels_out_f16_u8(fie_ctx* ctx, const void* src, int64_t ld_in, int H, int W, uint8_t* dst);
+
+/* ---- K9 latent prep.  Replaces DiagonalGaussianDistribution.sample, * scaling_factor, LCMScheduler.add_noise.
+ *   moments: f16 [H*W, 8] (mean 0..3, logvar 4..7); eps_post, noise: f32 [4, H*W] (NCHW draw order, as torch.randn
+ *   of shape [1,4,H,W]); latents_out: f32 [H*W, 4]; model_in: f16 [copies, H*W, 8] (zero padded). */
+int fie_latent_prep(fie_ctx* ctx, const void* moments, const float* eps_post, const float* noise, int64_t HW,
+                    float scaling_factor, float sqrt_ab, float sqrt_1mab, float* latents_out, void* model_in,
+                    int copies);
+
+/* ---- K8 CFG combine + LCMScheduler.step.  Replaces pipeline CFG line + scheduling_lcm.py::step.
+ *   eps: f16 [nb, H*W, ld_eps] (nb = 2 when guidance is applied: [uncond, cond]); latents: f32 [H*W, 4] (in/out);
+ *   noise: f32 [4, H*W] or NULL on the last step; model_in as in fie_latent_prep; denoised_out may be NULL. */
+int fie_lcm_step(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, float guidance, float* latents,
+                 const float* noise, int64_t HW, float sqrt_ab_t, float sqrt_1mab_t, float c_skip, float c_out,
+                 float sqrt_ab_prev, float sqrt_1mab_prev, void* model_in, int copies, float inv_scaling,
+                 void* decode_in);
+
+/* ---- weight repack (one-time, on device): src [N][K] f16 row-major (ld_src) -> dst [Npad][Kpad] zero padded.
+ *   conv: src is OIHW [Cout][Cin][3][3]; dst k-order (ky, kx, ci) with Cin padded to cin_pad.
+ *   interleave2 != 0: rows (j, j + N/2) become adjacent (GEGLU value/gate pairing). */
+int fie_pack_rows_f16(fie_ctx* ctx, const void* src, int64_t ld_src, int N, int K, void* dst, int64_t ldw,
+                      int Npad, int interleave2);
+int fie_pack_conv3x3_f16(fie_ctx* ctx, const void* src_oihw, int Cout, int Cin, int cin_pad, void* dst,
+                         int64_t ldw, int Npad);
+
+/* ---- K11 Canny on the host (integer exact).  Replaces cv2.cvtColor(RGB2GRAY) + cv2.Canny at
+ * src/pipeline.py:200,205 and the 3-channel stack at :208.  rgb, edges_rgb: host u8 [H, W, 3]. */
+int fie_canny_rgb_u8(const uint8_t* rgb, int H, int W, int low, int high, uint8_t* edges_rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIE_H_ */

@@ -1,0 +1,221 @@
+"""Op-level parity of every HIP kernel (through the C ABI) against a plain torch fp32 reference of the same op.
+Tolerances: fp16 storage + fp32 accumulation -> rel. error of the output tensor <= 3e-3 of its max-abs
+(stated per test); integer/byte outputs are exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 256), (1024, 1280, 1280), (77, 640, 2048), (3, 1280, 320), (4096, 640, 2560),
+                                   (130, 200, 72), (16384, 320, 320)])
+def test_gemm_plain(fie, m, n, k):
+    a, w = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5)
+    bias = rnd(n, seed=3)
+    ref = a.float() @ w.float().T + bias.float()
+    wp = fie.pack_linear(w.to(DEV))
+    out = fie.gemm(a.to(DEV), wp, n, bias=bias.to(DEV))
+    assert rel_err(out, ref) < 3e-3
+
+
+def test_gemm_asymmetric_identity(fie):
+    # A = I with an asymmetric W catches a swapped row/col map (guide: "Always A=I-check with ASYMMETRIC B")
+    n = k = 128
+    a = torch.eye(k).half()
+    w = (torch.arange(n)[:, None] * 0.5 + torch.arange(k)[None, :] * 0.01).half()
+    out = fie.gemm(a.to(DEV), fie.pack_linear(w.to(DEV)), n)
+    assert torch.equal(out.cpu(), w.T.contiguous())
+
+
+@pytest.mark.parametrize("act", ["silu", "gelu", "quick_gelu", "geglu"])
+def test_gemm_epilogues(fie, act):
+    from fie_amd import hip
+    m, n, k = 300, 512, 192
+    a, w, bias, res = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5), rnd(n, seed=3), rnd(m, n, seed=4)
+    rowb = rnd(3, n, seed=5)
+    lin = a.float() @ w.float().T + bias.float()
+    if act == "geglu":
+        v, g = lin.chunk(2, dim=-1)
+        ref = v * F.gelu(g) * 0.5
+        out = fie.gemm(a.to(DEV), fie.pack_linear(w.to(DEV), geglu=True), n,
+                       bias=torch.stack([bias[: n // 2], bias[n // 2:]], 1).reshape(-1).contiguous().to(DEV),
+                       scale=0.5, act=hip.ACT_GEGLU)
+    else:
+        lin = lin + rowb.float().repeat_interleave(100, 0)
+        fn = {"silu": F.silu, "gelu": F.gelu, "quick_gelu": lambda x: x * torch.sigmoid(1.702 * x)}[act]
+        ref = fn(lin) * 0.5 + res.float()
+        code = {"silu": hip.ACT_SILU, "gelu": hip.ACT_GELU, "quick_gelu": hip.ACT_QUICK_GELU}[act]
+        out = fie.gemm(a.to(DEV), fie.pack_linear(w.to(DEV)), n, bias=bias.to(DEV), rowbias=rowb.to(DEV),
+                       rows_per_batch=100, residual=res.to(DEV), scale=0.5, act=code)
+    assert rel_err(out, ref) < 3e-3
+
+
+def test_gemm_concat_a(fie):
+    m, k1, k2, n = 500, 128, 64, 256
+    a1, a2, w = rnd(m, k1, seed=1), rnd(m, k2, seed=2), rnd(n, k1 + k2, seed=3, scale=0.07)
+    ref = torch.cat([a1, a2], 1).float() @ w.float().T
+    out = fie.gemm(a1.to(DEV), fie.pack_linear(w.to(DEV)), n, a2=a2.to(DEV))
+    assert rel_err(out, ref) < 3e-3
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,stride,pad_mode,ups", [
+    (1, 32, 32, 64, 64, 1, 0, False), (2, 16, 16, 320, 640, 1, 0, False), (1, 32, 32, 128, 128, 2, 0, False),
+    (1, 32, 32, 64, 64, 2, 1, False), (1, 16, 16, 64, 128, 1, 0, True), (1, 64, 64, 8, 32, 1, 0, False),
+    (1, 24, 40, 16, 16, 1, 0, False), (1, 32, 32, 96, 256, 2, 0, False), (1, 128, 128, 320, 4, 1, 0, False)])
+def test_conv3x3(fie, b, h, w, cin, cout, stride, pad_mode, ups):
+    x = rnd(b, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    bias = rnd(cout, seed=3)
+    xi = x.float()
+    if ups:
+        xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+    if pad_mode == 1:
+        xi = F.pad(xi, (0, 1, 0, 1))
+    ref = F.conv2d(xi, wt.float(), bias.float(), stride=stride, padding=1 if pad_mode == 0 else 0)
+    out = fie.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), fie.pack_conv3x3(wt.to(DEV)), cout, stride=stride,
+                      pad_mode=pad_mode, upsample=ups, bias=bias.to(DEV))
+    assert out.shape[1:3] == ref.shape[2:]
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 3e-3
+
+
+def test_conv3x3_padded_cin_and_epilogue(fie):
+    from fie_amd import hip
+    # 3-channel image stored 8-channel padded; rowbias (time embedding) + residual + SiLU
+    b, h, w, cin, cout = 2, 32, 32, 3, 64
+    x, wt = rnd(b, cin, h, w, seed=1), rnd(cout, cin, 3, 3, seed=2, scale=0.2)
+    tb, res = rnd(b, cout, seed=3), rnd(b, cout, h, w, seed=4)
+    ref = F.silu(F.conv2d(x.float(), wt.float(), None, padding=1) + tb.float()[:, :, None, None]) + res.float()
+    xp = torch.zeros(b, h, w, 8, dtype=torch.float16)
+    xp[..., :3] = x.permute(0, 2, 3, 1)
+    out = fie.conv3x3(xp.to(DEV), fie.pack_conv3x3(wt.to(DEV), cin_pad=8), cout, rowbias=tb.to(DEV),
+                      residual=res.permute(0, 2, 3, 1).contiguous().to(DEV), act=hip.ACT_SILU)
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 3e-3
+
+
+@pytest.mark.parametrize("b,hn,tq,tk,d,causal", [(1, 10, 4096, 4096, 64, False), (2, 20, 1024, 1024, 64, False),
+                                                 (2, 10, 4096, 77, 64, False), (1, 12, 77, 77, 64, True),
+                                                 (1, 3, 200, 333, 64, False), (1, 1, 1024, 1024, 512, False),
+                                                 (1, 1, 100, 100, 512, False)])
+def test_attention(fie, b, hn, tq, tk, d, causal):
+    c = hn * d
+    q, k, v = rnd(b * tq, c, seed=1), rnd(b * tk, c, seed=2), rnd(b * tk, c, seed=3)
+    qf = q.float().view(b, tq, hn, d).transpose(1, 2)
+    kf = k.float().view(b, tk, hn, d).transpose(1, 2)
+    vf = v.float().view(b, tk, hn, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qf, kf, vf, is_causal=causal).transpose(1, 2).reshape(b * tq, c)
+    out = fie.attention(q.to(DEV), k.to(DEV), v.to(DEV), hn, d, tq, tk, b, causal=causal)
+    assert rel_err(out, ref) < 4e-3
+
+
+def test_attention_fused_qkv_strides(fie):
+    # q, k, v as column slices of one fused projection buffer (row stride 3C)
+    b, hn, t, d = 1, 4, 256, 64
+    c = hn * d
+    qkv = rnd(b * t, 3 * c, seed=7).to(DEV)
+    out = fie.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], hn, d, t, t, b)
+    f = qkv.float().cpu()
+    sp = lambda x: x.reshape(b, t, hn, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(f[:, :c]), sp(f[:, c:2 * c]), sp(f[:, 2 * c:])).transpose(1, 2).reshape(b * t, c)
+    assert rel_err(out, ref) < 4e-3
+
+
+def test_attention_forced_rescale(fie):
+    # spike one late key so the running max jumps mid-sequence (exercises the online-softmax rescale path)
+    b, hn, t, d = 1, 1, 512, 64
+    q, k, v = rnd(t, d, seed=1), rnd(t, d, seed=2), rnd(t, d, seed=3)
+    k[300] = q[5] * 4
+    ref = F.scaled_dot_product_attention(q.float()[None, None], k.float()[None, None], v.float()[None, None])[0, 0]
+    out = fie.attention(q.to(DEV), k.to(DEV), v.to(DEV), hn, d, t, t, b)
+    assert rel_err(out, ref) < 4e-3
+
+
+@pytest.mark.parametrize("b,rows,c1,c2,groups,silu", [(1, 1024, 320, 0, 32, True), (2, 256, 1280, 640, 32, True),
+                                                      (1, 4096, 128, 0, 32, False), (1, 256, 1280, 1280, 32, True),
+                                                      (1, 100, 64, 0, 32, True), (1, 65536, 128, 0, 32, True),
+                                                      (2, 1024, 640, 320, 32, True)])
+def test_groupnorm(fie, b, rows, c1, c2, groups, silu):
+    x1 = rnd(b, rows, c1, seed=1) + 0.5
+    x2 = rnd(b, rows, c2, seed=2) * 2 if c2 else None
+    c = c1 + c2
+    gamma, beta = rnd(c, seed=3), rnd(c, seed=4)
+    xc = torch.cat([x1, x2], -1) if c2 else x1
+    ref = F.group_norm(xc.float().transpose(1, 2), groups, gamma.float(), beta.float(), 1e-5).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    out = fie.groupnorm(x1.to(DEV), gamma.to(DEV), beta.to(DEV), groups, 1e-5, silu, x2=x2.to(DEV) if c2 else None)
+    assert rel_err(out, ref) < 3e-3
+
+
+@pytest.mark.parametrize("rows,c", [(4096, 640), (1024, 1280), (77, 768), (5, 64)])
+def test_layernorm(fie, rows, c):
+    x, g, bta = rnd(rows, c, seed=1) * 3 + 1, rnd(c, seed=2), rnd(c, seed=3)
+    ref = F.layer_norm(x.float(), (c,), g.float(), bta.float(), 1e-5)
+    out = fie.layernorm(x.to(DEV), g.to(DEV), bta.to(DEV))
+    assert rel_err(out, ref) < 3e-3
+
+
+def test_sinusoid_known_answers(fie):
+    # SURVEY A.1 KAT: t = 499, dim 320
+    out = torch.zeros(1, 320, device=DEV, dtype=torch.float16)
+    fie.sinusoid(torch.tensor([[499.0]], device=DEV), 320, out)
+    o = out.float().cpu()[0]
+    assert torch.allclose(o[0:3], torch.tensor([-0.87116218, 0.98838931, 0.19755381]), atol=2e-3)
+    assert torch.allclose(o[160:163], torch.tensor([0.49099535, -0.15194249, -0.98029202]), atol=2e-3)
+
+
+def test_pixels_roundtrip_exact(fie):
+    rng = np.random.default_rng(0)
+    img = torch.from_numpy(rng.integers(0, 256, (64, 48, 3), dtype=np.uint8))
+    x = fie.pixels_in(img.to(DEV), True, copies=2)
+    ref = 2.0 * (img.float() / 255.0) - 1.0
+    assert torch.allclose(x[1, ..., :3].float().cpu(), ref, atol=1e-3) and x[..., 3:].abs().max() == 0
+    back = fie.pixels_out(x[:1])
+    assert torch.equal(back.cpu(), img)          # u8 -> f16 -> u8 is the identity
+
+
+def test_lcm_step_and_latent_prep(fie):
+    hw = 32 * 32
+    g = torch.Generator().manual_seed(0)
+    mom = torch.randn(hw, 8, generator=g).half()
+    e1, e2 = torch.randn(4, hw, generator=g), torch.randn(4, hw, generator=g)
+    lat = torch.empty(hw, 4, device=DEV)
+    mi = torch.empty(2, hw, 8, device=DEV, dtype=torch.float16)
+    fie.latent_prep(mom.to(DEV), e1.to(DEV), e2.to(DEV), hw, 0.13025, 0.5269, 0.8499, lat, mi)
+    mean, logvar = mom.float()[:, :4], mom.float()[:, 4:].clamp(-30, 20)
+    z0 = (mean + torch.exp(0.5 * logvar) * e1.T) * 0.13025
+    ref = 0.5269 * z0 + 0.8499 * e2.T
+    assert torch.allclose(lat.cpu(), ref, atol=1e-5)
+    assert torch.allclose(mi[1, :, :4].float().cpu(), ref, atol=2e-3) and mi[..., 4:].abs().max() == 0
+    eps = torch.randn(2, hw, 4, generator=g).half()
+    z = torch.randn(4, hw, generator=g)
+    dec = torch.empty(hw, 8, device=DEV, dtype=torch.float16)
+    fie.lcm_step(eps.to(DEV), 2, 1.5, lat, z.to(DEV), hw, 0.5269, 0.8499, 1e-8, 1.0, 0.8118, 0.5840, mi, 1 / 0.13025, dec)
+    e = eps[0].float() + 1.5 * (eps[1].float() - eps[0].float())
+    x0 = (ref - 0.8499 * e) / 0.5269
+    ref2 = 0.8118 * (1.0 * x0 + 1e-8 * ref) + 0.5840 * z.T
+    assert torch.allclose(lat.cpu(), ref2, atol=1e-4)
+    assert torch.allclose(dec[:, :4].float().cpu(), ref2 / 0.13025, rtol=2e-3, atol=2e-3)
+
+
+def test_clip_embed(fie):
+    tok, pos = rnd(1000, 64, seed=1), rnd(77, 64, seed=2)
+    ids = torch.randint(0, 1000, (2, 77), dtype=torch.int32)
+    out = fie.clip_embed(ids.to(DEV), tok.to(DEV), pos.to(DEV))
+    ref = (tok.float()[ids.long()] + pos.float()[None]).reshape(-1, 64)
+    assert rel_err(out, ref) < 2e-3
