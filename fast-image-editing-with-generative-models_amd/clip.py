@@ -1,0 +1,56 @@
+"""CLIP text encoders on HIP kernels (upstream transformers modeling_clip.py).
+
+Pre-LN transformer, causal 77x77 attention (head dim 64 in both CLIP-L and OpenCLIP-bigG), returns what
+encode_prompt() consumes: hidden_states[-2] (penultimate layer, before the final LayerNorm) and -- for the
+encoder with a projection -- the projected final-LN state at the EOS position."""
+import torch
+
+from . import hip
+from .nn import Linear, Norm, F16, _dev
+
+
+class ClipText:
+    def __init__(self, ctx, cfg, sd):
+        self.ctx, self.cfg = ctx, cfg
+        self.tok = _dev(ctx, sd["text_model.embeddings.token_embedding.weight"])
+        self.pos = _dev(ctx, sd["text_model.embeddings.position_embedding.weight"])
+        self.layers = []
+        for i in range(cfg["layers"]):
+            p = f"text_model.encoder.layers.{i}."
+            w = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+            b = torch.cat([sd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+            self.layers.append(dict(
+                ln1=Norm(ctx, sd, p + "layer_norm1"), qkv=Linear(ctx, None, None, w=w, b=b),
+                out=Linear(ctx, sd, p + "self_attn.out_proj"), ln2=Norm(ctx, sd, p + "layer_norm2"),
+                fc1=Linear(ctx, sd, p + "mlp.fc1"), fc2=Linear(ctx, sd, p + "mlp.fc2")))
+        self.final_ln = Norm(ctx, sd, "text_model.final_layer_norm")
+        self.proj = Linear(ctx, None, None, w=sd["text_projection.weight"]) if cfg["projection_dim"] else None
+        self.act = hip.ACT_QUICK_GELU if cfg["act"] == "quick_gelu" else hip.ACT_GELU
+
+    def __call__(self, ids):
+        """ids: int tensor [B, T] (host or device).  Returns (penultimate [B*T, C] f16, pooled [B, P] f16 or None)."""
+        ctx, cfg = self.ctx, self.cfg
+        b, t = ids.shape
+        c, heads = cfg["hidden"], cfg["heads"]
+        x = ctx.clip_embed(ids.to(ctx.device, torch.int32).contiguous(), self.tok, self.pos)
+        n_run = cfg["layers"] if self.proj is not None else cfg["layers"] - 1   # last layer only feeds the pooled output
+        penult = None
+        for i in range(n_run):
+            if i == cfg["layers"] - 1:
+                penult = x
+            L = self.layers[i]
+            y = ctx.layernorm(x, L["ln1"].g, L["ln1"].b, cfg["eps"])
+            qkv = L["qkv"](ctx, y)
+            a = ctx.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], heads, c // heads, t, t, b, causal=True)
+            x = L["out"](ctx, a, residual=x)
+            y = ctx.layernorm(x, L["ln2"].g, L["ln2"].b, cfg["eps"])
+            x = L["fc2"](ctx, L["fc1"](ctx, y, act=self.act), residual=x)
+        if penult is None:
+            penult = x
+        pooled = None
+        if self.proj is not None:
+            last = ctx.layernorm(x, self.final_ln.g, self.final_ln.b, cfg["eps"])
+            eos = (ids.to("cpu") == cfg["eos_token_id"]).int().argmax(dim=-1)      # first EOS (host index logic)
+            rows = (torch.arange(b) * t + eos).to(ctx.device)
+            pooled = self.proj(ctx, last.index_select(0, rows))
+        return penult, pooled

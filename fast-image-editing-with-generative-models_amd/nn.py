@@ -1,0 +1,314 @@
+"""Host-side graph sequencing for the UNet / ControlNet: packs diffusers-named weights
+into the kernel layouts once, then issues the HIP kernels of csrc/ through the C ABI in graph order.
+
+Activations are NHWC fp16 ([B, H, W, C]; token views [B*H*W, C] share the same memory).  What is fused where:
+  * resnet:        GN+SiLU kernel -> conv1 (+bias, +time-embedding row bias) -> GN+SiLU -> conv2 (+bias, +shortcut/identity residual)
+  * up-block cat:  never materialised -- GroupNorm and the 1x1 shortcut GEMM read the two halves directly
+  * up/downsample: nearest-2x gather / stride 2 folded into the conv's im2col addressing
+  * transformer:   fused QKV GEMM; attention reads q/k/v as strided column views; out-proj/FF2 GEMMs add the residual;
+                   FF1 is one GEMM with the GEGLU epilogue; cross-attention K/V of the (step-invariant) text are cached
+  * time-embedding projections of ALL resnets are one GEMM per step (their weights are concatenated at load)
+  * ControlNet zero-convs scale by conditioning_scale and add straight into the UNet skip tensors (GEMM epilogue)
+"""
+import torch
+
+from . import hip
+from .presets import time_embed_dim
+
+F16 = torch.float16
+
+
+def _dev(ctx, t):
+    return t.to(ctx.device, F16).contiguous()
+
+
+class Linear:
+    def __init__(self, ctx, sd, name, geglu=False, w=None, b=None):
+        w = sd[name + ".weight"] if w is None else w
+        b = sd.get(name + ".bias") if b is None and name else b
+        w = w.reshape(w.shape[0], -1)
+        self.n, self.k = w.shape
+        self.act = hip.ACT_GEGLU if geglu else hip.ACT_NONE
+        self.wp = ctx.pack_linear(w, geglu=geglu)
+        if b is not None:
+            b = _dev(ctx, b)
+            if geglu:
+                b = torch.stack([b[: self.n // 2], b[self.n // 2:]], 1).reshape(-1).contiguous()
+        self.b = b
+
+    def __call__(self, ctx, a, a2=None, residual=None, act=None, scale=1.0, out=None, rowbias=None, rows_per_batch=0):
+        return ctx.gemm(a, self.wp, self.n, a2=a2, bias=self.b, residual=residual, scale=scale, out=out,
+                        act=self.act if act is None else act, rowbias=rowbias, rows_per_batch=rows_per_batch)
+
+
+class Conv3:
+    def __init__(self, ctx, sd, name, cin_pad=None, cout_pad=None):
+        w = sd[name + ".weight"]
+        self.cout, self.cin = w.shape[:2]
+        self.cin_pad = cin_pad or (self.cin + 7) // 8 * 8
+        self.ldc = cout_pad or self.cout
+        self.n = (self.cout + 3) // 4 * 4          # kernel writes whole 4-channel groups (extra ones are zeros)
+        self.wp = ctx.pack_conv3x3(w, self.cin_pad)
+        b = sd.get(name + ".bias")
+        if b is not None:
+            bb = torch.zeros(self.n, dtype=F16, device=ctx.device)
+            bb[: self.cout] = b.to(ctx.device, F16)
+            b = bb
+        self.b = b
+
+    def __call__(self, ctx, x, stride=1, pad_mode=0, upsample=False, rowbias=None, residual=None, act=hip.ACT_NONE):
+        return ctx.conv3x3(x, self.wp, self.n, stride=stride, pad_mode=pad_mode, upsample=upsample, bias=self.b,
+                           rowbias=rowbias, residual=residual, act=act, ldc=max(self.ldc, self.n))
+
+
+class Norm:
+    def __init__(self, ctx, sd, name):
+        self.g, self.b = _dev(ctx, sd[name + ".weight"]), _dev(ctx, sd[name + ".bias"])
+
+
+class Resnet:
+    def __init__(self, ctx, sd, p, groups, eps, temb_slot=None):
+        self.groups, self.eps = groups, eps
+        self.n1, self.n2 = Norm(ctx, sd, p + "norm1"), Norm(ctx, sd, p + "norm2")
+        self.c1, self.c2 = Conv3(ctx, sd, p + "conv1"), Conv3(ctx, sd, p + "conv2")
+        self.sc = Linear(ctx, sd, p + "conv_shortcut") if p + "conv_shortcut.weight" in sd else None
+        self.temb_slot = temb_slot              # (col0, col1) into the fused time-embedding projection
+
+    def __call__(self, ctx, x, temb_all=None, skip=None):
+        b, h, w, _ = x.shape
+        y = ctx.groupnorm(x, self.n1.g, self.n1.b, self.groups, self.eps, True, x2=skip)
+        rb = temb_all[:, self.temb_slot[0]:self.temb_slot[1]] if self.temb_slot is not None else None
+        y = self.c1(ctx, y, rowbias=rb)
+        y = ctx.groupnorm(y, self.n2.g, self.n2.b, self.groups, self.eps, True)
+        if self.sc is not None:
+            res = self.sc(ctx, x.view(b * h * w, -1), a2=None if skip is None else skip.view(b * h * w, -1))
+            res = res.view(b, h, w, -1)
+        else:
+            res = x
+        return self.c2(ctx, y, residual=res)
+
+
+class TBlock:
+    def __init__(self, ctx, sd, p, c, head_dim):
+        self.c, self.heads, self.hd = c, c // head_dim, head_dim
+        self.ln = [Norm(ctx, sd, p + f"norm{i}") for i in (1, 2, 3)]
+        wqkv = torch.cat([sd[p + f"attn1.to_{n}.weight"] for n in "qkv"], 0)
+        self.qkv = Linear(ctx, None, None, w=wqkv)
+        self.o1 = Linear(ctx, sd, p + "attn1.to_out.0")
+        self.q2 = Linear(ctx, sd, p + "attn2.to_q")
+        self.kv2 = Linear(ctx, None, None, w=torch.cat([sd[p + "attn2.to_k.weight"], sd[p + "attn2.to_v.weight"]], 0))
+        self.o2 = Linear(ctx, sd, p + "attn2.to_out.0")
+        self.ff1 = Linear(ctx, sd, p + "ff.net.0.proj", geglu=True)
+        self.ff2 = Linear(ctx, sd, p + "ff.net.2")
+        self.kv_cache = None
+
+    def __call__(self, ctx, h, text, batch, tokens, text_len):
+        c = self.c
+        y = ctx.layernorm(h, self.ln[0].g, self.ln[0].b)
+        qkv = self.qkv(ctx, y)
+        a = ctx.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], self.heads, self.hd, tokens, tokens, batch)
+        h = self.o1(ctx, a, residual=h)
+        y = ctx.layernorm(h, self.ln[1].g, self.ln[1].b)
+        q = self.q2(ctx, y)
+        if self.kv_cache is None:                 # text is invariant over the denoising steps of one image
+            self.kv_cache = self.kv2(ctx, text)
+        kv = self.kv_cache
+        a = ctx.attention(q, kv[:, :c], kv[:, c:], self.heads, self.hd, tokens, text_len, batch)
+        h = self.o2(ctx, a, residual=h)
+        y = ctx.layernorm(h, self.ln[2].g, self.ln[2].b)
+        f = self.ff1(ctx, y)
+        return self.ff2(ctx, f, residual=h)
+
+
+class Transformer2D:
+    def __init__(self, ctx, sd, p, c, depth, head_dim, groups):
+        self.groups = groups
+        self.norm = Norm(ctx, sd, p + "norm")
+        self.pin, self.pout = Linear(ctx, sd, p + "proj_in"), Linear(ctx, sd, p + "proj_out")
+        self.blocks = [TBlock(ctx, sd, f"{p}transformer_blocks.{k}.", c, head_dim) for k in range(depth)]
+
+    def __call__(self, ctx, x, text, text_len):
+        b, hh, ww, c = x.shape
+        xt = x.view(b * hh * ww, c)
+        h = ctx.groupnorm(x, self.norm.g, self.norm.b, self.groups, 1e-6, False).view(b * hh * ww, c)
+        h = self.pin(ctx, h)
+        for blk in self.blocks:
+            h = blk(ctx, h, text, b, hh * ww, text_len)
+        return self.pout(ctx, h, residual=xt).view(b, hh, ww, c)
+
+    def reset(self):
+        for blk in self.blocks:
+            blk.kv_cache = None
+
+
+class _CondNet:
+    """conv_in + time/text-time embedding + down blocks + mid block: the half shared by UNet and ControlNet."""
+
+    def __init__(self, ctx, cfg, sd):
+        self.ctx, self.cfg = ctx, cfg
+        g, eps, hd = cfg["norm_num_groups"], cfg["norm_eps"], cfg["head_dim"]
+        chans = cfg["block_out_channels"]
+        self.temb_names = []                      # resnet prefixes in fused-projection order
+        self.conv_in = Conv3(ctx, sd, "conv_in", cin_pad=8)
+        self.t1, self.t2 = Linear(ctx, sd, "time_embedding.linear_1"), Linear(ctx, sd, "time_embedding.linear_2")
+        self.a1, self.a2 = Linear(ctx, sd, "add_embedding.linear_1"), Linear(ctx, sd, "add_embedding.linear_2")
+        self.down = []
+        for i in range(len(chans)):
+            layers = []
+            for j in range(cfg["layers_per_block"]):
+                r = self._resnet(sd, f"down_blocks.{i}.resnets.{j}.", g, eps)
+                d = cfg["down_attn"][i][j]
+                t = Transformer2D(ctx, sd, f"down_blocks.{i}.attentions.{j}.", chans[i], d, hd, g) if d else None
+                layers.append((r, t))
+            ds = Conv3(ctx, sd, f"down_blocks.{i}.downsamplers.0.conv") if i != len(chans) - 1 else None
+            self.down.append((layers, ds))
+        self.mid = [(self._resnet(sd, "mid_block.resnets.0.", g, eps), None)]
+        for k in range(1, cfg["mid_resnets"]):
+            t = Transformer2D(ctx, sd, f"mid_block.attentions.{k - 1}.", chans[-1], cfg["mid_attn"], hd, g) \
+                if cfg["mid_attn"] else None
+            self.mid.append((self._resnet(sd, f"mid_block.resnets.{k}.", g, eps), t))
+        self._sd = sd
+
+    def _resnet(self, sd, p, g, eps):
+        r = Resnet(self.ctx, sd, p, g, eps)
+        self.temb_names.append((p, r))
+        return r
+
+    def _finish_temb(self, sd):
+        """Concatenate every resnet's time_emb_proj into one [sum Cout, temb] GEMM."""
+        ws, bs, col = [], [], 0
+        for p, r in self.temb_names:
+            w = sd[p + "time_emb_proj.weight"]
+            ws.append(w)
+            bs.append(sd[p + "time_emb_proj.bias"])
+            r.temb_slot = (col, col + w.shape[0])
+            col += w.shape[0]
+        self.temb_proj = Linear(self.ctx, None, None, w=torch.cat(ws, 0), b=torch.cat(bs, 0))
+        self._sd = None
+
+    def transformers(self):
+        for layers, _ in self.down:
+            for _, t in layers:
+                if t:
+                    yield t
+        for _, t in self.mid:
+            if t:
+                yield t
+
+    def begin_image(self, pooled, time_ids):
+        """Per-image invariants: the text-time addition embedding; drops the cross-attention K/V caches."""
+        ctx, cfg = self.ctx, self.cfg
+        b = pooled.shape[0]
+        ad = cfg["addition_time_embed_dim"]
+        add_in = torch.empty((b, cfg["projection_class_embeddings_input_dim"]), device=ctx.device, dtype=F16)
+        add_in[:, : pooled.shape[1]] = pooled
+        ctx.sinusoid(time_ids, ad, add_in, col0=pooled.shape[1])
+        self.add_emb = self.a2(ctx, self.a1(ctx, add_in, act=hip.ACT_SILU))
+        for t in self.transformers():
+            t.reset()
+
+    def time_rowbias(self, t_dev):
+        """silu(time_emb + add_emb) -> all resnets' time projections in one GEMM.  t_dev: f32 [B, 1] on device."""
+        ctx = self.ctx
+        ch0 = self.cfg["block_out_channels"][0]
+        s = torch.empty((t_dev.shape[0], ch0), device=ctx.device, dtype=F16)
+        ctx.sinusoid(t_dev, ch0, s)
+        # emb = time_emb + add_emb; resnets consume Linear(SiLU(emb)): add_emb rides in as a per-row bias so the
+        # second MLP GEMM's epilogue emits SiLU(emb) directly
+        semb = self.t2(ctx, self.t1(ctx, s, act=hip.ACT_SILU), rowbias=self.add_emb, rows_per_batch=1, act=hip.ACT_SILU)
+        return self.temb_proj(ctx, semb)
+
+    def encode(self, x, temb_all, text, text_len):
+        ctx = self.ctx
+        skips = [x]
+        for layers, ds in self.down:
+            for r, t in layers:
+                x = r(ctx, x, temb_all)
+                if t:
+                    x = t(ctx, x, text, text_len)
+                skips.append(x)
+            if ds is not None:
+                x = ds(ctx, x, stride=2)
+                skips.append(x)
+        for r, t in self.mid:
+            if t:
+                x = t(ctx, x, text, text_len)
+            x = r(ctx, x, temb_all)
+        return skips, x
+
+
+class UNet(_CondNet):
+    def __init__(self, ctx, cfg, sd):
+        super().__init__(ctx, cfg, sd)
+        g, eps, hd = cfg["norm_num_groups"], cfg["norm_eps"], cfg["head_dim"]
+        rev = list(reversed(cfg["block_out_channels"]))
+        self.up = []
+        for i in range(len(rev)):
+            layers = []
+            for j in range(cfg["layers_per_block"] + 1):
+                r = self._resnet(sd, f"up_blocks.{i}.resnets.{j}.", g, eps)
+                d = cfg["up_attn"][i][j]
+                t = Transformer2D(ctx, sd, f"up_blocks.{i}.attentions.{j}.", rev[i], d, hd, g) if d else None
+                layers.append((r, t))
+            us = Conv3(ctx, sd, f"up_blocks.{i}.upsamplers.0.conv") if i != len(rev) - 1 else None
+            self.up.append((layers, us))
+        self.norm_out = Norm(ctx, sd, "conv_norm_out")
+        self.conv_out = Conv3(ctx, sd, "conv_out")
+        self._finish_temb(sd)
+
+    def transformers(self):
+        yield from super().transformers()
+        for layers, _ in self.up:
+            for _, t in layers:
+                if t:
+                    yield t
+
+    def decode(self, x, skips, temb_all, text, text_len):
+        ctx, cfg = self.ctx, self.cfg
+        skips = list(skips)
+        for layers, us in self.up:
+            for r, t in layers:
+                x = r(ctx, x, temb_all, skip=skips.pop())
+                if t:
+                    x = t(ctx, x, text, text_len)
+            if us is not None:
+                x = us(ctx, x, upsample=True)
+        y = ctx.groupnorm(x, self.norm_out.g, self.norm_out.b, cfg["norm_num_groups"], cfg["norm_eps"], True)
+        return self.conv_out(ctx, y)              # [B, H, W, 4]
+
+
+class ControlNet(_CondNet):
+    def __init__(self, ctx, cfg, sd):
+        super().__init__(ctx, cfg, sd)
+        p = "controlnet_cond_embedding."
+        nb = len(cfg["conditioning_embedding_out_channels"]) - 1
+        self.ce_in = Conv3(ctx, sd, p + "conv_in", cin_pad=8)
+        self.ce_blocks = [(Conv3(ctx, sd, f"{p}blocks.{2 * i}"), Conv3(ctx, sd, f"{p}blocks.{2 * i + 1}")) for i in range(nb)]
+        self.ce_out = Conv3(ctx, sd, p + "conv_out")
+        n_skip = 1 + sum(cfg["layers_per_block"] + (1 if i != len(cfg["block_out_channels"]) - 1 else 0)
+                         for i in range(len(cfg["block_out_channels"])))
+        self.zero = [Linear(ctx, sd, f"controlnet_down_blocks.{i}") for i in range(n_skip)]
+        self.zero_mid = Linear(ctx, sd, "controlnet_mid_block")
+        self._finish_temb(sd)
+
+    def cond_embedding(self, cond):
+        """The edge-map embedding does not depend on the timestep: computed once per image. cond: [B,H,W,8] in [0,1]."""
+        ctx = self.ctx
+        c = self.ce_in(ctx, cond, act=hip.ACT_SILU)
+        for a, b in self.ce_blocks:
+            c = a(ctx, c, act=hip.ACT_SILU)
+            c = b(ctx, c, stride=2, act=hip.ACT_SILU)
+        return self.ce_out(ctx, c)
+
+    def add_residuals(self, x_in, cond_emb, temb_all, text, text_len, scale, unet_skips, unet_mid):
+        """ControlNet forward whose zero-conv epilogues write `unet_skip + scale * zero_conv(.)` directly."""
+        ctx = self.ctx
+        x = self.conv_in(ctx, x_in, residual=cond_emb)          # sample = conv_in(x) + cond_embedding
+        skips, mid = self.encode(x, temb_all, text, text_len)
+        out = []
+        for z, s, u in zip(self.zero, skips, unet_skips):
+            b, h, w, c = s.shape
+            out.append(z(ctx, s.view(-1, c), scale=scale, residual=u.view(-1, c)).view(b, h, w, c))
+        b, h, w, c = mid.shape
+        m = self.zero_mid(ctx, mid.view(-1, c), scale=scale, residual=unet_mid.view(-1, c)).view(b, h, w, c)
+        return out, m

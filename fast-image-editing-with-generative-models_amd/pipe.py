@@ -1,0 +1,130 @@
+"""The object `FastEditor` stores in ``self.pipe``: same call signature as the diffusers
+StableDiffusionXLControlNetImg2ImgPipeline call at /root/reference/src/pipeline.py:261-272, but every stage
+(CLIP text, VAE encode, ControlNet + UNet evaluations, CFG + LCM step, VAE decode, pixel conversion) runs in the
+hand-written HIP kernels of csrc/ (call order: SURVEY.md 3.2 steps 1-9)."""
+import types
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import hip
+from .clip import ClipText
+from .lcm import LCMSchedule
+from .nn import ControlNet, UNet
+from .presets import LCM_SCHED
+from .tokenizer import StandInTokenizer
+from .vae import VAE
+
+F16 = torch.float16
+
+
+class HipImg2ImgPipeline:
+    def __init__(self, ctx, cfgs, sds, tokenizers=None, sched_cfg=None, noise_dtype=torch.float16):
+        """cfgs / sds: dicts with keys unet, controlnet, vae, clip_l, clip_g (configs / diffusers-named state dicts)."""
+        self.ctx, self.cfgs = ctx, cfgs
+        self.unet = UNet(ctx, cfgs["unet"], sds["unet"])
+        self.controlnet = ControlNet(ctx, cfgs["controlnet"], sds["controlnet"])
+        self.vae = VAE(ctx, cfgs["vae"], sds["vae"])
+        self.clip_l = ClipText(ctx, cfgs["clip_l"], sds["clip_l"])
+        self.clip_g = ClipText(ctx, cfgs["clip_g"], sds["clip_g"])
+        self.tok_l, self.tok_g = tokenizers or (StandInTokenizer(cfgs["clip_l"]["pad_token_id"]),
+                                                StandInTokenizer(cfgs["clip_g"]["pad_token_id"]))
+        self.scheduler = LCMSchedule(**(sched_cfg or LCM_SCHED))
+        self.noise_dtype = noise_dtype
+        self.progress = {}
+        self.last_stats = {}
+
+    # -- diffusers API surface the reference touches
+    def set_progress_bar_config(self, **kw):          # run_batch.py:157-158
+        self.progress.update(kw)
+
+    def _randn(self, shape, generator):
+        """diffusers utils/torch_utils.py::randn_tensor: a CPU generator draws on the host and the result is moved;
+        a device generator draws on the device.  Drawn in `noise_dtype` (the pipeline dtype upstream)."""
+        gdev = generator.device.type if generator is not None else self.ctx.device.type
+        if gdev == "cpu":
+            x = torch.randn(shape, generator=generator, device="cpu", dtype=self.noise_dtype).to(self.ctx.device)
+        else:
+            x = torch.randn(shape, generator=generator, device=self.ctx.device, dtype=self.noise_dtype)
+        return x.float().contiguous()
+
+    def encode_prompt(self, texts):
+        """texts: list of strings -> ([len*77, Dl+Dg] f16, pooled [len, P] f16)."""
+        pl, _ = self.clip_l(self.tok_l(texts))
+        pg, pooled = self.clip_g(self.tok_g(texts))
+        return torch.cat([pl, pg], dim=1), pooled
+
+    @torch.no_grad()
+    def __call__(self, prompt, negative_prompt="", image=None, control_image=None, strength=0.8,
+                 num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5, generator=None,
+                 output_type="pil", **unused):
+        ctx = self.ctx
+        if image is None or control_image is None:
+            raise ValueError("`image` and `control_image` are both required")
+        if strength < 0 or strength > 1:
+            raise ValueError(f"The value of strength should in [0.0, 1.0] but is {strength}")
+        if image.size != control_image.size:
+            raise ValueError("image and control_image must have the same size")
+        w, h = image.size
+        if h % 8 or w % 8:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {h} and {w}.")
+        steps = self.scheduler.plan(num_inference_steps, strength)
+        if not steps:
+            raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of "
+                             f"pipeline steps is 0 which is < 1 and not appropriate for this pipeline.")
+        do_cfg = guidance_scale > 1.0
+        nb = 2 if do_cfg else 1
+        dev = ctx.device
+
+        # 1-2. text encoders (negative prompt "" is really encoded: SURVEY 0 item 4)
+        texts = [negative_prompt or "", prompt] if do_cfg else [prompt]
+        text, pooled = self.encode_prompt(texts)
+        text_len = text.shape[0] // nb
+
+        # 3. pixels -> device tensors
+        img_u8 = torch.from_numpy(np.ascontiguousarray(np.asarray(image.convert("RGB")))).to(dev)
+        ctl_u8 = torch.from_numpy(np.ascontiguousarray(np.asarray(control_image.convert("RGB")))).to(dev)
+        x_img = ctx.pixels_in(img_u8, True)
+        cond = ctx.pixels_in(ctl_u8, False, copies=nb)
+
+        # 5. prepare_latents: VAE posterior sample (draw #1), init noise (draw #2), add_noise
+        moments, (lh, lw) = self.vae.encode_moments(x_img)
+        hw = lh * lw
+        eps_post = self._randn((1, 4, lh, lw), generator)
+        noise = self._randn((1, 4, lh, lw), generator)
+        latents = torch.empty((hw, 4), device=dev, dtype=torch.float32)
+        model_in = torch.empty((nb, lh, lw, 8), device=dev, dtype=F16)
+        sf = self.cfgs["vae"]["scaling_factor"]
+        ctx.latent_prep(moments, eps_post, noise, hw, sf, steps[0]["sqrt_ab"], steps[0]["sqrt_1mab"], latents, model_in)
+
+        # 6. per-image invariants
+        time_ids = torch.tensor([[h, w, 0, 0, h, w]], dtype=torch.float32, device=dev).repeat(nb, 1)
+        self.unet.begin_image(pooled, time_ids)
+        self.controlnet.begin_image(pooled, time_ids)
+        cond_emb = self.controlnet.cond_embedding(cond)
+        decode_in = torch.empty((1, lh, lw, 8), device=dev, dtype=F16)
+
+        # 7. denoising loop
+        for st in steps:
+            t_dev = torch.full((nb, 1), float(st["t"]), device=dev, dtype=torch.float32)
+            tb_u = self.unet.time_rowbias(t_dev)
+            tb_c = self.controlnet.time_rowbias(t_dev)
+            skips, mid = self.unet.encode(self.unet.conv_in(ctx, model_in), tb_u, text, text_len)
+            skips, mid = self.controlnet.add_residuals(model_in, cond_emb, tb_c, text, text_len,
+                                                       controlnet_conditioning_scale, skips, mid)
+            eps = self.unet.decode(mid, skips, tb_u, text, text_len)
+            z = None if st["last"] else self._randn((1, 4, lh, lw), generator)
+            ctx.lcm_step(eps, nb, guidance_scale, latents, z, hw, st["sqrt_ab"], st["sqrt_1mab"], st["c_skip"],
+                         st["c_out"], st["sqrt_ab_prev"], st["sqrt_1mab_prev"], model_in, 1.0 / sf, decode_in)
+
+        # 8-9. decode + postprocess
+        dec = self.vae.decode(decode_in)
+        out_u8 = ctx.pixels_out(dec)
+        self.last_stats = dict(unet_evals=len(steps), cfg_batch=nb, latent_hw=(lh, lw))
+        if output_type == "latent":
+            return types.SimpleNamespace(images=[latents.view(lh, lw, 4).clone()])
+        arr = out_u8.cpu().numpy()                     # device -> host sync, as `.images[0]` implies upstream
+        if output_type == "np":
+            return types.SimpleNamespace(images=[arr])
+        return types.SimpleNamespace(images=[Image.fromarray(arr)])

@@ -1,0 +1,4 @@
+"""Drop-in for the reference's `src` package (src/__init__.py:4-7): `from src.pipeline import FastEditor`."""
+from .pipeline import FastEditor
+
+__all__ = ["FastEditor"]

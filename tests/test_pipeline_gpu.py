@@ -1,0 +1,151 @@
+"""Stage-by-stage and end-to-end parity of the HIP hot path against the CPU fp32 oracle on identical seeds,
+weights (fp16-rounded on both sides) and noise (drawn fp32 on a CPU generator: SURVEY 8a-RNG build rule).
+
+Tolerances (fp16 storage, fp32 accumulation vs an fp32 reference): per-tensor max-abs error relative to the
+tensor's max-abs <= 2e-2 for deep composite graphs; the north_star image gate is SSIM >= 0.99."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+def synth_image(seed, size):
+    """Low-frequency colour field + filled shapes, so Canny(100,200) finds real edges."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    img = np.stack([0.5 + 0.4 * np.sin(6.0 * xx + rng.uniform(0, 6)) * np.cos(4.0 * yy + rng.uniform(0, 6))
+                    for _ in range(3)], axis=2)
+    for _ in range(6):
+        cx, cy, r = rng.uniform(0.1, 0.9), rng.uniform(0.1, 0.9), rng.uniform(0.05, 0.2)
+        mask = ((xx - cx) ** 2 + (yy - cy) ** 2) < r * r
+        img[mask] = rng.uniform(0, 1, 3)
+    x0, x1 = sorted(rng.integers(0, size, 2))
+    y0, y1 = sorted(rng.integers(0, size, 2))
+    img[y0:y1, x0:x1] = rng.uniform(0, 1, 3)
+    return Image.fromarray((img.clip(0, 1) * 255).astype(np.uint8))
+
+
+@pytest.fixture(scope="module", params=["tiny", "tiny-nomid"])
+def rig(request, fie):
+    from fie_amd import stack
+    from fie_amd.pipe import HipImg2ImgPipeline
+    cfgs, sds = stack.synthetic_stack(request.param, True, device="cpu", dtype=torch.float16)
+    sds32 = {k: {n: v.float() for n, v in sd.items()} for k, sd in sds.items()}
+    pipe = HipImg2ImgPipeline(fie, cfgs, sds, noise_dtype=torch.float32)
+    return cfgs, sds32, pipe
+
+
+def _ids(pipe, texts):
+    return pipe.tok_l(texts), pipe.tok_g(texts)
+
+
+def test_clip_text_parity(rig):
+    from oracle import nets
+    cfgs, sds32, pipe = rig
+    il, ig = _ids(pipe, ["a [rusty] bicycle on the road", ""])
+    for enc, cfg, sd, ids in ((pipe.clip_l, cfgs["clip_l"], sds32["clip_l"], il), (pipe.clip_g, cfgs["clip_g"], sds32["clip_g"], ig)):
+        pen, pooled = enc(ids)
+        hs, ref_pooled = nets.clip_text_forward(sd, cfg, ids)
+        assert rel_err(pen.view(2, 77, -1), hs[-2]) < 1e-2
+        if pooled is not None:
+            assert rel_err(pooled, ref_pooled) < 1e-2
+
+
+def test_vae_roundtrip_parity(rig, fie):
+    from oracle import nets, pipeline as opipe
+    cfgs, sds32, pipe = rig
+    img = synth_image(3, 128)
+    x = opipe.pil_to_float(img, True)
+    mean, logvar = nets.vae_encode_moments(sds32["vae"], cfgs["vae"], x)
+    u8 = torch.from_numpy(np.asarray(img)).cuda()
+    mom, (lh, lw) = pipe.vae.encode_moments(fie.pixels_in(u8, True))
+    ref = torch.cat([mean, logvar], 1)[0].permute(1, 2, 0).reshape(lh * lw, 8)
+    assert rel_err(mom, ref) < 2e-2
+    z = torch.zeros(1, lh, lw, 8, dtype=torch.float16)
+    z[..., :4] = mean[0].permute(1, 2, 0).half()
+    dec = pipe.vae.decode(z.cuda())
+    ref_dec = nets.vae_decode(sds32["vae"], cfgs["vae"], mean.half().float())
+    assert rel_err(dec[0, ..., :3].permute(2, 0, 1), ref_dec[0]) < 2e-2
+
+
+def test_unet_controlnet_eval_parity(rig, fie):
+    """One ControlNet + UNet evaluation with CFG batch 2 on shared inputs."""
+    from oracle import nets
+    cfgs, sds32, pipe = rig
+    g = torch.Generator().manual_seed(5)
+    lh = lw = 16
+    lat = torch.randn(2, 4, lh, lw, generator=g).half().float()
+    cond = (torch.rand(2, 3, lh * 8, lw * 8, generator=g) > 0.9).float()
+    xd = cfgs["unet"]["cross_attention_dim"]
+    text = torch.randn(2, 77, xd, generator=g).half().float()
+    pdim = cfgs["unet"]["projection_class_embeddings_input_dim"] - 6 * cfgs["unet"]["addition_time_embed_dim"]
+    pooled = torch.randn(2, pdim, generator=g).half().float()
+    tid = torch.tensor([[128., 128., 0, 0, 128., 128.]]).repeat(2, 1)
+    t = 499
+    down, mid = nets.controlnet_forward(sds32["controlnet"], cfgs["controlnet"], lat, t, text, cond, 0.5, pooled, tid)
+    ref = nets.unet_forward(sds32["unet"], cfgs["unet"], lat, t, text, pooled, tid, down, mid)
+
+    dev = fie.device
+    model_in = torch.zeros(2, lh, lw, 8, dtype=torch.float16, device=dev)
+    model_in[..., :4] = lat.permute(0, 2, 3, 1).half().to(dev)
+    cond8 = torch.zeros(2, lh * 8, lw * 8, 8, dtype=torch.float16, device=dev)
+    cond8[..., :3] = cond.permute(0, 2, 3, 1).half().to(dev)
+    text_d = text.reshape(2 * 77, xd).half().to(dev)
+    pipe.unet.begin_image(pooled.half().to(dev), tid.to(dev))
+    pipe.controlnet.begin_image(pooled.half().to(dev), tid.to(dev))
+    cemb = pipe.controlnet.cond_embedding(cond8)
+    t_dev = torch.full((2, 1), float(t), device=dev)
+    tb_u, tb_c = pipe.unet.time_rowbias(t_dev), pipe.controlnet.time_rowbias(t_dev)
+    skips, m = pipe.unet.encode(pipe.unet.conv_in(fie, model_in), tb_u, text_d, 77)
+    skips2, m2 = pipe.controlnet.add_residuals(model_in, cemb, tb_c, text_d, 77, 0.5, skips, m)
+    eps = pipe.unet.decode(m2, skips2, tb_u, text_d, 77)
+    assert rel_err(eps.permute(0, 3, 1, 2), ref) < 2e-2
+
+
+@pytest.mark.parametrize("guidance,strength", [(1.5, 0.8), (1.0, 0.5), (2.0, 1.0)])
+def test_full_pipeline_parity(rig, guidance, strength):
+    from oracle import canny, metrics, pipeline as opipe
+    cfgs, sds32, pipe = rig
+    img = synth_image(11, 128)
+    ctrl = Image.fromarray(canny.canny_rgb(np.asarray(img)))
+    prompt, neg = "a [red] circle next to a square", ""
+    out = pipe(prompt=prompt, negative_prompt=neg, image=img, control_image=ctrl, strength=strength,
+               num_inference_steps=4, guidance_scale=guidance, controlnet_conditioning_scale=0.5,
+               generator=torch.Generator("cpu").manual_seed(42)).images[0]
+    tr = {}
+    ref = opipe.run(sds32, cfgs, img, ctrl, _ids(pipe, [prompt]), _ids(pipe, [neg]), strength=strength,
+                    num_inference_steps=4, guidance_scale=guidance, controlnet_conditioning_scale=0.5,
+                    generator=torch.Generator("cpu").manual_seed(42), trace=tr)
+    assert pipe.last_stats["unet_evals"] == len(tr["eps"]) == int(4 * strength)
+    s = metrics.ssim(out, ref, size=None)
+    diff = np.abs(np.asarray(out).astype(int) - ref.astype(int))
+    print(f"ssim={s:.5f} max|du8|={diff.max()} mean|du8|={diff.mean():.4f}")
+    assert s >= 0.99
+
+
+def test_editor_api_surface(fie):
+    from src.pipeline import FastEditor
+    with pytest.raises(ValueError):
+        FastEditor(model_name="nope")
+    ed = FastEditor(model_name="tiny", enable_cpu_offload=False, use_full_controlnet=True)
+    assert set(FastEditor.MODEL_CONFIGS) == {"sdxl", "ssd-1b"}
+    ed.pipe.set_progress_bar_config(disable=True)
+    img = synth_image(1, 96)
+    edge = ed.preprocess_image(img)
+    assert edge.size == img.size and set(np.unique(np.asarray(edge))) <= {0, 255}
+    out = ed.edit(img, "a photo of a [cat]", seed=42, strength=0.5, guidance_scale=1.0)
+    assert out.size == (1024, 1024) and out.mode == "RGB"
+    out2 = ed.edit(img, "a photo of a [cat]", seed=42, strength=0.5, guidance_scale=1.0)
+    assert np.array_equal(np.asarray(out), np.asarray(out2))         # same seed -> same image
+    mem = ed.get_memory_usage()
+    assert mem["allocated_gb"] > 0 and "reserved_gb" in mem
+    with pytest.raises(ValueError):
+        ed.edit(img, "x", strength=1.5)
+    ed.clear_memory()
