@@ -83,7 +83,7 @@ def _tiny(unet_like):
     c = deepcopy(unet_like)
     c["name"] = "tiny-" + c["name"]
     c["block_out_channels"] = (64, 128, 256)
-    c["cross_attention_dim"] = 128
+    c["cross_attention_dim"] = 192           # tiny CLIP-L hidden 128 + tiny CLIP-G hidden 64
     c["addition_time_embed_dim"] = 32
     # pooled text dim 64 (tiny bigG projection) + 6 * 32
     c["projection_class_embeddings_input_dim"] = 64 + 6 * 32
@@ -100,7 +100,7 @@ TINY_UNET = _tiny(UNET_SDXL)
 TINY_UNET_NOMID = _tiny(UNET_SSD1B_A1)
 TINY_CONTROLNET = _tiny(CONTROLNET_FULL)
 TINY_VAE = dict(VAE_SDXL, name="tiny-vae", block_out_channels=(32, 64, 64, 64))
-TINY_CLIP_L = dict(CLIP_L, name="tiny-clip-l", hidden=64, layers=2, heads=2, intermediate=128, vocab_size=49408)
+TINY_CLIP_L = dict(CLIP_L, name="tiny-clip-l", hidden=128, layers=2, heads=2, intermediate=256, vocab_size=49408)
 TINY_CLIP_G = dict(CLIP_BIGG, name="tiny-clip-g", hidden=64, layers=3, heads=1, intermediate=128, projection_dim=64)
 
 # what `FastEditor(model_name=...)` resolves to; "tiny" is a test-only stack with the same topology
