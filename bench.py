@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PIE-Bench images/sec @1024^2, SSD-1B fp16, nominal 4-step LCM img2img with Canny ControlNet
+(BASELINE.json metric; workload = configs[1]).  One "step" = one full edit of one synthetic PIE-Bench-shaped item
+(CLIP x2, VAE encode, evals x (ControlNet + UNet), CFG + LCM steps, VAE decode, u8 conversion), inputs already
+resident in HBM when the timed region starts.  Image-parallel over N GPUs: every rank edits its own items with a
+full replica; no collective inside the timed region except the bracketing barriers.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (UNet forward, fp16 MFMA bound,
+HIP-event timed) and `cpu_baseline` (oracle/ fp32 restatement timed on this host, rank 0, N=1 only)."""
+import argparse
+import csv
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: Peak BF16/FP16 MFMA ~2.5 PF dense
+
+
+def synth_item_image(i, size=512):
+    """PIE-Bench-shaped synthetic source image: low-frequency colour fields + filled shapes."""
+    from PIL import Image
+    rng = np.random.default_rng(i)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    img = np.stack([0.5 + 0.4 * np.sin(rng.uniform(2, 9) * xx + rng.uniform(0, 6)) * np.cos(rng.uniform(2, 9) * yy + rng.uniform(0, 6))
+                    for _ in range(3)], axis=2)
+    for _ in range(8):
+        cx, cy, r = rng.uniform(0.1, 0.9), rng.uniform(0.1, 0.9), rng.uniform(0.04, 0.2)
+        img[((xx - cx) ** 2 + (yy - cy) ** 2) < r * r] = rng.uniform(0, 1, 3)
+    for _ in range(3):
+        x0, x1 = sorted(rng.integers(0, size, 2))
+        y0, y1 = sorted(rng.integers(0, size, 2))
+        img[y0:y1, x0:x1] = rng.uniform(0, 1, 3)
+    return Image.fromarray((img.clip(0, 1) * 255).astype(np.uint8))
+
+
+def load_items():
+    with open(os.path.join(ROOT, "tests", "golden", "pie_bench_items.csv")) as f:
+        return list(csv.DictReader(f))
+
+
+def cpu_baseline(editor, cfgs, job_args, evals, nb):
+    """Time the CPU fp32 oracle on a bounded sample: CLIP (batch nb) + VAE encode + ONE ControlNet+UNet evaluation at
+    batch 1 + VAE decode at 1024^2, then assemble the benchmark configuration's time from those parts."""
+    from oracle import nets, pipeline as opipe
+    from fie_amd import weights
+    torch.set_num_threads(os.cpu_count())
+    seeds = {"unet": 0, "controlnet": 1, "vae": 2, "clip_l": 3, "clip_g": 4}
+    # same synthetic generator as the product, fp16-rounded like the device copy (values do not affect timing)
+    sds = {k: {n: v.float() for n, v in weights.synth_state_dict(cfgs[k], seed=1234 + s, dtype=torch.float16).items()}
+           for k, s in seeds.items()}
+    pipe = editor.pipe
+    img, ctrl, prompt = job_args
+    with torch.no_grad():
+        t0 = time.time()
+        ids = (pipe.tok_l([prompt] * nb), pipe.tok_g([prompt] * nb))
+        pe, pooled = opipe.encode_prompt(sds, cfgs, *ids)
+        t_clip = time.time() - t0
+        t0 = time.time()
+        x = opipe.pil_to_float(img, True)
+        mean, _ = nets.vae_encode_moments(sds["vae"], cfgs["vae"], x)
+        t_enc = time.time() - t0
+        lat = mean * cfgs["vae"]["scaling_factor"]
+        cond = opipe.pil_to_float(ctrl, False)
+        tid = torch.tensor([[1024., 1024., 0, 0, 1024., 1024.]])
+        t0 = time.time()
+        down, mid = nets.controlnet_forward(sds["controlnet"], cfgs["controlnet"], lat, 499, pe[:1], cond, 0.5, pooled[:1], tid)
+        eps = nets.unet_forward(sds["unet"], cfgs["unet"], lat, 499, pe[:1], pooled[:1], tid, down, mid)
+        t_eval = time.time() - t0
+        t0 = time.time()
+        nets.vae_decode(sds["vae"], cfgs["vae"], (lat - 0.1 * eps) / cfgs["vae"]["scaling_factor"])
+        t_dec = time.time() - t0
+    est = t_clip + t_enc + t_dec + evals * nb * t_eval
+    return {"value": 1.0 / est, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+            "sample": (f"oracle/ fp32 torch-CPU restatement, 1 image 1024^2: CLIPx2 batch {nb} {t_clip:.1f}s + VAE encode "
+                       f"{t_enc:.1f}s + one ControlNet+UNet eval at batch 1 {t_eval:.1f}s + VAE decode {t_dec:.1f}s measured; "
+                       f"image time assembled as clip + enc + dec + {evals}x{nb} evals = {est:.1f}s")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="ssd-1b", choices=["ssd-1b", "sdxl"])
+    ap.add_argument("--controlnet", default="full", choices=["full", "small"])
+    ap.add_argument("--strength", type=float, default=0.5)
+    ap.add_argument("--guidance", type=float, default=1.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a launcher with WORLD_SIZE={args.gpus} (torch.distributed.run)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import contextlib
+    import io
+    from src.pipeline import FastEditor
+    from fie_amd import flops
+    with contextlib.redirect_stdout(io.StringIO() if rank else sys.stderr):
+        editor = FastEditor(model_name=args.model, device=f"cuda:{local}" if world > 1 else "cuda",
+                            enable_cpu_offload=False, use_full_controlnet=args.controlnet == "full")
+    pipe = editor.pipe
+    cfgs = pipe.cfgs
+    items = load_items()
+    total = args.warmup + args.steps
+
+    # image-parallel shard: rank r takes items r, r+W, ...; weak scaling = K items per rank
+    from PIL import Image
+    jobs, first = [], None
+    for s in range(total):
+        it = items[(rank + s * world) % len(items)]
+        src = synth_item_image(int(it["image_id"]) % 100000 + s)
+        inp = src.resize((1024, 1024), Image.LANCZOS)
+        ctrl = editor.preprocess_image(inp)
+        gen = torch.Generator(device="cpu").manual_seed(42)
+        jobs.append(pipe.prepare(it["editing_prompt"], "", inp, ctrl, args.strength, 4, args.guidance, 0.5, gen))
+        if first is None:
+            first = (inp, ctrl, it["editing_prompt"], src)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        pipe.run_device(jobs[s])
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total):
+        pipe.run_device(jobs[s])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    evals, nb = pipe.last_stats["unet_evals"], pipe.last_stats["cfg_batch"]
+    value = args.steps * world / elapsed
+
+    # ---- roofline of the UNet forward, HIP-event timed on the launch stream (2 extra untimed-for-throughput passes)
+    stage = {}
+    for s in range(2):
+        pipe.timing = []
+        pipe.run_device(jobs[args.warmup + s % max(args.steps, 1)])
+        for k, v in pipe.stage_ms().items():
+            stage[k] = stage.get(k, 0.0) + v / 2
+    pipe.timing = None
+    fl = flops.image_flops(cfgs, evals, nb)
+    unet_ms_per_fwd = stage["unet"] / evals
+    unet_tflops = fl["unet"] * nb / (unet_ms_per_fwd * 1e-3) / 1e12
+    image_tflops = fl["total"] / (sum(stage.values()) * 1e-3) / 1e12
+
+    # ---- end-to-end (PIL in -> PIL out: LANCZOS, Canny, H2D, device, D2H) as run_batch.py:208-221 times it
+    t1 = time.perf_counter()
+    for s in range(2):
+        editor.edit(first[3], first[2], strength=args.strength, guidance_scale=args.guidance, seed=42)
+    e2e = (time.perf_counter() - t1) / 2
+
+    if rank == 0:
+        out = {
+            "metric": "PIE-Bench images/sec @1024^2 SSD-1B fp16 4-step", "value": round(value, 4), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic (seeded PIE-Bench-shaped 512^2 images, real PIE-Bench prompts, seeded random-init weights, stand-in tokenizer)",
+            "config": {"workload": f"{args.model} fp16 + ControlNet-Canny({args.controlnet}) LCM img2img, num_inference_steps=4, "
+                                   f"strength={args.strength}, guidance={args.guidance}, 1024x1024, batch=1 image per GPU",
+                       "unet_preset": cfgs["unet"]["name"], "controlnet_preset": cfgs["controlnet"]["name"],
+                       "unet_evals": evals, "cfg_batch": nb, "parallelism": f"image-parallel x{world}",
+                       "tflop_per_image": round(fl["total"] / 1e12, 2)},
+            "roofline": {"bound": "mfma", "kernel": f"UNet forward ({cfgs['unet']['name']}, batch {nb}): all launches between the "
+                                                    "HIP events bracketing unet.encode + unet.decode",
+                         "achieved": round(unet_tflops, 2), "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(unet_tflops / PEAK_F16_DENSE_TFLOPS, 4), "traffic": None,
+                         "algorithmic_tflop": round(fl["unet"] * nb / 1e12, 3), "ms": round(unet_ms_per_fwd, 3)},
+            "stage_ms": {k: round(v, 2) for k, v in stage.items()},
+            "image_tflops": round(image_tflops, 2),
+            "e2e_images_per_sec": round(1.0 / e2e, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(editor, cfgs, first[:3], evals, nb)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,7 @@ class HipImg2ImgPipeline:
         self.noise_dtype = noise_dtype
         self.progress = {}
         self.last_stats = {}
+        self.timing = None         # set to [] to collect per-stage HIP-event timings in run_device()
 
     # -- diffusers API surface the reference touches
     def set_progress_bar_config(self, **kw):          # run_batch.py:157-158
@@ -55,10 +56,10 @@ class HipImg2ImgPipeline:
         pg, pooled = self.clip_g(self.tok_g(texts))
         return torch.cat([pl, pg], dim=1), pooled
 
-    @torch.no_grad()
-    def __call__(self, prompt, negative_prompt="", image=None, control_image=None, strength=0.8,
-                 num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5, generator=None,
-                 output_type="pil", **unused):
+    def prepare(self, prompt, negative_prompt="", image=None, control_image=None, strength=0.8,
+                num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5, generator=None):
+        """Host side of one call: argument checks, tokenisation, RNG draws (in upstream order: posterior sample, init
+        noise, one per non-final step) and the H2D copies.  Returns the device-resident job for run_device()."""
         ctx = self.ctx
         if image is None or control_image is None:
             raise ValueError("`image` and `control_image` are both required")
@@ -74,56 +75,100 @@ class HipImg2ImgPipeline:
             raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of "
                              f"pipeline steps is 0 which is < 1 and not appropriate for this pipeline.")
         do_cfg = guidance_scale > 1.0
-        nb = 2 if do_cfg else 1
         dev = ctx.device
-
-        # 1-2. text encoders (negative prompt "" is really encoded: SURVEY 0 item 4)
         texts = [negative_prompt or "", prompt] if do_cfg else [prompt]
-        text, pooled = self.encode_prompt(texts)
-        text_len = text.shape[0] // nb
+        lh, lw = h // 8, w // 8
+        u8 = lambda im: torch.from_numpy(np.array(im.convert("RGB"))).to(dev)
+        n_noise = 2 + sum(1 for st in steps if not st["last"])
+        return dict(
+            ids_l=self.tok_l(texts).to(dev, torch.int32), ids_g=self.tok_g(texts).to(dev, torch.int32),
+            eos_g=(self.tok_g(texts) == self.cfgs["clip_g"]["eos_token_id"]).int().argmax(dim=-1),
+            img_u8=u8(image), ctl_u8=u8(control_image), hw=(h, w), steps=steps, nb=2 if do_cfg else 1,
+            guidance=float(guidance_scale), cn_scale=float(controlnet_conditioning_scale),
+            noises=[self._randn((1, 4, lh, lw), generator) for _ in range(n_noise)])
 
-        # 3. pixels -> device tensors
-        img_u8 = torch.from_numpy(np.ascontiguousarray(np.asarray(image.convert("RGB")))).to(dev)
-        ctl_u8 = torch.from_numpy(np.ascontiguousarray(np.asarray(control_image.convert("RGB")))).to(dev)
-        x_img = ctx.pixels_in(img_u8, True)
-        cond = ctx.pixels_in(ctl_u8, False, copies=nb)
+    def _mark(self, name):
+        if self.timing is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.timing.append((name, ev))
 
-        # 5. prepare_latents: VAE posterior sample (draw #1), init noise (draw #2), add_noise
-        moments, (lh, lw) = self.vae.encode_moments(x_img)
+    @torch.no_grad()
+    def run_device(self, job):
+        """Device side: everything between the H2D and D2H copies.  Returns the u8 HWC image on the device."""
+        ctx, dev = self.ctx, self.ctx.device
+        h, w = job["hw"]
+        nb, steps = job["nb"], job["steps"]
+        lh, lw = h // 8, w // 8
         hw = lh * lw
-        eps_post = self._randn((1, 4, lh, lw), generator)
-        noise = self._randn((1, 4, lh, lw), generator)
+        self._mark("start")
+        # 1-2. text encoders (negative prompt "" is really encoded: SURVEY 0 item 4)
+        pl, _ = self.clip_l(job["ids_l"])
+        pg, pooled = self.clip_g(job["ids_g"], eos=job["eos_g"])
+        text = torch.cat([pl, pg], dim=1)
+        text_len = text.shape[0] // nb
+        self._mark("clip")
+        # 3. pixels
+        x_img = ctx.pixels_in(job["img_u8"], True)
+        cond = ctx.pixels_in(job["ctl_u8"], False, copies=nb)
+        # 5. prepare_latents: VAE posterior sample (draw #1), init noise (draw #2), add_noise
+        moments, _ = self.vae.encode_moments(x_img)
+        noises = list(job["noises"])
         latents = torch.empty((hw, 4), device=dev, dtype=torch.float32)
         model_in = torch.empty((nb, lh, lw, 8), device=dev, dtype=F16)
         sf = self.cfgs["vae"]["scaling_factor"]
-        ctx.latent_prep(moments, eps_post, noise, hw, sf, steps[0]["sqrt_ab"], steps[0]["sqrt_1mab"], latents, model_in)
-
+        ctx.latent_prep(moments, noises.pop(0), noises.pop(0), hw, sf, steps[0]["sqrt_ab"], steps[0]["sqrt_1mab"],
+                        latents, model_in)
+        self._mark("vae_encode")
         # 6. per-image invariants
         time_ids = torch.tensor([[h, w, 0, 0, h, w]], dtype=torch.float32, device=dev).repeat(nb, 1)
         self.unet.begin_image(pooled, time_ids)
         self.controlnet.begin_image(pooled, time_ids)
         cond_emb = self.controlnet.cond_embedding(cond)
         decode_in = torch.empty((1, lh, lw, 8), device=dev, dtype=F16)
-
+        self._mark("cond_embed")
         # 7. denoising loop
         for st in steps:
             t_dev = torch.full((nb, 1), float(st["t"]), device=dev, dtype=torch.float32)
             tb_u = self.unet.time_rowbias(t_dev)
             tb_c = self.controlnet.time_rowbias(t_dev)
+            self._mark("embed")
             skips, mid = self.unet.encode(self.unet.conv_in(ctx, model_in), tb_u, text, text_len)
-            skips, mid = self.controlnet.add_residuals(model_in, cond_emb, tb_c, text, text_len,
-                                                       controlnet_conditioning_scale, skips, mid)
+            self._mark("unet")
+            skips, mid = self.controlnet.add_residuals(model_in, cond_emb, tb_c, text, text_len, job["cn_scale"],
+                                                       skips, mid)
+            self._mark("controlnet")
             eps = self.unet.decode(mid, skips, tb_u, text, text_len)
-            z = None if st["last"] else self._randn((1, 4, lh, lw), generator)
-            ctx.lcm_step(eps, nb, guidance_scale, latents, z, hw, st["sqrt_ab"], st["sqrt_1mab"], st["c_skip"],
+            self._mark("unet")
+            z = None if st["last"] else noises.pop(0)
+            ctx.lcm_step(eps, nb, job["guidance"], latents, z, hw, st["sqrt_ab"], st["sqrt_1mab"], st["c_skip"],
                          st["c_out"], st["sqrt_ab_prev"], st["sqrt_1mab_prev"], model_in, 1.0 / sf, decode_in)
-
+            self._mark("lcm_step")
         # 8-9. decode + postprocess
         dec = self.vae.decode(decode_in)
         out_u8 = ctx.pixels_out(dec)
+        self._mark("vae_decode")
         self.last_stats = dict(unet_evals=len(steps), cfg_batch=nb, latent_hw=(lh, lw))
+        self._latents = latents
+        return out_u8
+
+    def stage_ms(self):
+        """Per-stage device milliseconds of the last run_device() (needs `self.timing = []` before the call)."""
+        torch.cuda.synchronize()
+        out = {}
+        for (_, e0), (name, e1) in zip(self.timing[:-1], self.timing[1:]):
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        return out
+
+    def __call__(self, prompt, negative_prompt="", image=None, control_image=None, strength=0.8,
+                 num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5, generator=None,
+                 output_type="pil", **unused):
+        job = self.prepare(prompt, negative_prompt, image, control_image, strength, num_inference_steps,
+                           guidance_scale, controlnet_conditioning_scale, generator)
+        out_u8 = self.run_device(job)
         if output_type == "latent":
-            return types.SimpleNamespace(images=[latents.view(lh, lw, 4).clone()])
+            lh, lw = self.last_stats["latent_hw"]
+            return types.SimpleNamespace(images=[self._latents.view(lh, lw, 4).clone()])
         arr = out_u8.cpu().numpy()                     # device -> host sync, as `.images[0]` implies upstream
         if output_type == "np":
             return types.SimpleNamespace(images=[arr])
