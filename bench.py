@@ -43,6 +43,10 @@ def synth_item_image(i, size=512):
     return Image.fromarray((img.clip(0, 1) * 255).astype(np.uint8))
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def load_items():
     with open(os.path.join(ROOT, "tests", "golden", "pie_bench_items.csv")) as f:
         return list(csv.DictReader(f))
@@ -56,19 +60,24 @@ def cpu_baseline(editor, cfgs, job_args, evals, nb):
     torch.set_num_threads(os.cpu_count())
     seeds = {"unet": 0, "controlnet": 1, "vae": 2, "clip_l": 3, "clip_g": 4}
     # same synthetic generator as the product, fp16-rounded like the device copy (values do not affect timing)
-    sds = {k: {n: v.float() for n, v in weights.synth_state_dict(cfgs[k], seed=1234 + s, dtype=torch.float16).items()}
-           for k, s in seeds.items()}
+    sds = {}
+    for k, s in seeds.items():
+        log(f"cpu_baseline: generating {k} weights on the host")
+        sds[k] = {n: v.float() for n, v in weights.synth_state_dict(cfgs[k], seed=1234 + s, dtype=torch.float16).items()}
     pipe = editor.pipe
     img, ctrl, prompt = job_args
+    log("cpu_baseline: weights ready, timing CLIP")
     with torch.no_grad():
         t0 = time.time()
         ids = (pipe.tok_l([prompt] * nb), pipe.tok_g([prompt] * nb))
         pe, pooled = opipe.encode_prompt(sds, cfgs, *ids)
         t_clip = time.time() - t0
+        log(f"cpu_baseline: clip {t_clip:.1f}s; timing VAE encode")
         t0 = time.time()
         x = opipe.pil_to_float(img, True)
         mean, _ = nets.vae_encode_moments(sds["vae"], cfgs["vae"], x)
         t_enc = time.time() - t0
+        log(f"cpu_baseline: vae encode {t_enc:.1f}s; timing one ControlNet+UNet eval")
         lat = mean * cfgs["vae"]["scaling_factor"]
         cond = opipe.pil_to_float(ctrl, False)
         tid = torch.tensor([[1024., 1024., 0, 0, 1024., 1024.]])
@@ -76,6 +85,7 @@ def cpu_baseline(editor, cfgs, job_args, evals, nb):
         down, mid = nets.controlnet_forward(sds["controlnet"], cfgs["controlnet"], lat, 499, pe[:1], cond, 0.5, pooled[:1], tid)
         eps = nets.unet_forward(sds["unet"], cfgs["unet"], lat, 499, pe[:1], pooled[:1], tid, down, mid)
         t_eval = time.time() - t0
+        log(f"cpu_baseline: eval {t_eval:.1f}s; timing VAE decode")
         t0 = time.time()
         nets.vae_decode(sds["vae"], cfgs["vae"], (lat - 0.1 * eps) / cfgs["vae"]["scaling_factor"])
         t_dec = time.time() - t0
@@ -135,6 +145,7 @@ def main():
         if first is None:
             first = (inp, ctrl, it["editing_prompt"], src)
     torch.cuda.synchronize()
+    log(f"{total} jobs resident on the device; warmup {args.warmup}, timed {args.steps}")
 
     def barrier():
         if dist is not None:
@@ -154,6 +165,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
     evals, nb = pipe.last_stats["unet_evals"], pipe.last_stats["cfg_batch"]
     value = args.steps * world / elapsed
 
@@ -175,6 +187,7 @@ def main():
     for s in range(2):
         editor.edit(first[3], first[2], strength=args.strength, guidance_scale=args.guidance, seed=42)
     e2e = (time.perf_counter() - t1) / 2
+    log(f"stage ms: { {k: round(v, 1) for k, v in stage.items()} }; e2e {e2e * 1e3:.1f} ms/image")
 
     if rank == 0:
         out = {
