@@ -47,6 +47,19 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def host_cores():
+    """Threads the CPU baseline may use: the process's CPU share (affinity / cgroup quota), capped at 16 (a one-GPU
+    box's share) -- os.cpu_count() reports the whole host and oversubscribes by an order of magnitude."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def load_items():
     with open(os.path.join(ROOT, "tests", "golden", "pie_bench_items.csv")) as f:
         return list(csv.DictReader(f))
@@ -57,7 +70,8 @@ def cpu_baseline(editor, cfgs, job_args, evals, nb):
     batch 1 + VAE decode at 1024^2, then assemble the benchmark configuration's time from those parts."""
     from oracle import nets, pipeline as opipe
     from fie_amd import weights
-    torch.set_num_threads(os.cpu_count())
+    cores = host_cores()
+    torch.set_num_threads(cores)
     seeds = {"unet": 0, "controlnet": 1, "vae": 2, "clip_l": 3, "clip_g": 4}
     # same synthetic generator as the product, fp16-rounded like the device copy (values do not affect timing)
     sds = {}
@@ -90,7 +104,7 @@ def cpu_baseline(editor, cfgs, job_args, evals, nb):
         nets.vae_decode(sds["vae"], cfgs["vae"], (lat - 0.1 * eps) / cfgs["vae"]["scaling_factor"])
         t_dec = time.time() - t0
     est = t_clip + t_enc + t_dec + evals * nb * t_eval
-    return {"value": 1.0 / est, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+    return {"value": 1.0 / est, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": (f"oracle/ fp32 torch-CPU restatement, 1 image 1024^2: CLIPx2 batch {nb} {t_clip:.1f}s + VAE encode "
                        f"{t_enc:.1f}s + one ControlNet+UNet eval at batch 1 {t_eval:.1f}s + VAE decode {t_dec:.1f}s measured; "
                        f"image time assembled as clip + enc + dec + {evals}x{nb} evals = {est:.1f}s")}

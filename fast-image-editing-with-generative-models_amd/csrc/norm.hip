@@ -84,22 +84,31 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(GnArgs p) {
     }
 }
 
-__global__ void gn_finalize_kernel(GnArgs p, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GnArgs p, int B) {
+    // one wave per (b, g): lanes stride over the chunk partials, xor-shuffle reduce in fp64
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B * p.G) return;
     const int b = i / p.G, g = i - b * p.G;
     double a = 0.0, q = 0.0;
-    for (int c = 0; c < p.nchunks; ++c) {
-        const float* src = p.partial + (((int64_t)b * p.nchunks + c) * p.G + g) * 2;
-        a += (double)src[0];
-        q += (double)src[1];
+    for (int c = lane; c < p.nchunks; c += 64) {
+        const float2 v = *reinterpret_cast<const float2*>(p.partial + (((int64_t)b * p.nchunks + c) * p.G + g) * 2);
+        a += (double)v.x;
+        q += (double)v.y;
     }
-    const double n = (double)p.rows * p.cg;
-    const double mean = a / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    p.stats[i * 2] = (float)mean;
-    p.stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        q += __shfl_xor(q, o);
+    }
+    if (lane == 0) {
+        const double n = (double)p.rows * p.cg;
+        const double mean = a / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        p.stats[i * 2] = (float)mean;
+        p.stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
@@ -234,7 +243,7 @@ int fie_groupnorm_nhwc_f16(fie_ctx* ctx, const void* X1, int C1, const void* X2,
     p.stats = p.partial + (int64_t)B * GN_MAX_CHUNKS * groups * 2;
     const dim3 grid((unsigned)p.nchunks, (unsigned)B, (unsigned)csplit);
     hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(GN_THREADS), 0, ctx->stream, p);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 255) / 256), dim3(256), 0, ctx->stream, p, B);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, ctx->stream, p, B);
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), 0, ctx->stream, p);
     FIE_LAUNCH_CHECK();
     return FIE_OK;

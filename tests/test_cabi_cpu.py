@@ -1,0 +1,126 @@
+"""CPU suite: the C-ABI shared library loads and exports every symbol include/fie.h declares (no GPU compute is
+called); the host-side Canny entry (the one ABI function that needs no device) matches the numpy oracle exactly;
+argument validation of device entries fails loudly without touching a GPU; CLI surfaces match the reference's flags."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import fie_amd  # noqa: F401
+from fie_amd import hip
+from oracle import canny as ocanny
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    hip.build()
+    return hip.lib()
+
+
+def test_header_symbols_all_exported(lib):
+    text = open(os.path.join(ROOT, "include", "fie.h")).read()
+    declared = set(re.findall(r"\b(fie_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/fie.h but not exported"
+    assert declared - {"fie_last_error"} == set(hip.SIGNATURES), "ctypes signature table out of sync with the header"
+    assert lib.fie_version() >= 100
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device"):
+        hip.Context(0)
+    from src.pipeline import FastEditor
+    with pytest.raises(RuntimeError):
+        FastEditor(model_name="ssd-1b", device="cpu")
+    with pytest.raises(ValueError, match="Unknown model"):
+        FastEditor(model_name="sd15")
+
+
+def _scene(seed, h, w):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([128 + 100 * np.sin(xx / rng.uniform(5, 30) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(5, 30))
+                    for _ in range(3)], 2)
+    for _ in range(10):
+        cx, cy, r = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(1, max(2, min(h, w) / 4))
+        img[((xx - cx) ** 2 + (yy - cy) ** 2) < r * r] = rng.uniform(0, 255, 3)
+    img += rng.normal(0, 6, img.shape)
+    return img.clip(0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("seed,h,w,lo,hi", [(0, 64, 64, 100, 200), (1, 97, 131, 100, 200), (2, 256, 256, 50, 150),
+                                            (3, 128, 64, 200, 100), (4, 1024, 1024, 100, 200), (5, 8, 8, 10, 20)])
+def test_canny_cabi_bit_exact_vs_oracle(lib, seed, h, w, lo, hi):
+    img = _scene(seed, h, w)
+    got = hip.canny_rgb(img, lo, hi)
+    ref = ocanny.canny_rgb(img, lo, hi)
+    assert got.dtype == np.uint8 and got.shape == img.shape
+    assert np.array_equal(got, ref)
+    if h >= 64:
+        assert 0 < (got > 0).mean() < 0.5
+
+
+def test_canny_edge_cases(lib):
+    assert hip.canny_rgb(np.zeros((1, 1, 3), np.uint8)).max() == 0
+    noise = np.random.default_rng(9).integers(0, 256, (50, 70, 3), dtype=np.uint8)
+    assert np.array_equal(hip.canny_rgb(noise), ocanny.canny_rgb(noise))
+    idem = hip.canny_rgb(noise)
+    assert set(np.unique(idem)) <= {0, 255}
+    with pytest.raises(hip.FieError):
+        hip._chk(lib.fie_canny_rgb_u8(None, 4, 4, 1, 2, None))
+    assert b"bad argument" in lib.fie_last_error()
+
+
+def _flags(parser):
+    return {a.option_strings[0]: (a.default, a.type, tuple(a.choices) if a.choices else None)
+            for a in parser._actions if a.option_strings and a.option_strings[0] != "-h"}
+
+
+def test_cli_flags_match_reference():
+    """Flag names/defaults of the reference CLIs (run_batch.py:45-87, run_single_image.py:19-41), plus additive ones."""
+    import run_batch
+    import run_single_image
+    fb = _flags(run_batch.build_parser())
+    ref_batch = {"--mapping_file": "data/PIE-Bench_v1/mapping_file.json", "--source_dir": "data/PIE-Bench_v1/annotation_images",
+                 "--output_dir": "outputs", "--model": "sdxl", "--num_images": None, "--editing_types": None,
+                 "--image_ids": None, "--steps": 4, "--guidance": 1.5, "--control_scale": 0.5, "--canny_low": 100,
+                 "--canny_high": 200, "--seed": None, "--negative_prompt": "", "--no_cpu_offload": False,
+                 "--quality_mode": False, "--full_precision": False, "--full_controlnet": False, "--skip_existing": False,
+                 "--save_comparisons": False}
+    for k, d in ref_batch.items():
+        assert k in fb and fb[k][0] == d, k
+    assert fb["--model"][2] == ("sdxl", "ssd-1b")
+    assert set(fb) - set(ref_batch) == {"--strength", "--weights_dir", "--results_json"}
+    fs = _flags(run_single_image.build_parser())
+    for k in ("--image", "--prompt", "--model", "--negative_prompt", "--steps", "--guidance", "--control_scale",
+              "--canny_low", "--canny_high", "--seed", "--output_dir", "--no_cpu_offload", "--quality_mode",
+              "--full_precision", "--full_controlnet", "--compute_metrics", "--show_plot"):
+        assert k in fs, k
+    assert fs["--guidance"][0] == 1.5 and fs["--steps"][0] == 4
+
+
+def test_safe_join_and_selection():
+    import argparse
+    import run_batch
+    assert run_batch.safe_join("/data/src", "0_random/a.jpg") == "/data/src/0_random/a.jpg"
+    for bad in ("../x.jpg", "/etc/passwd", "a/../../x"):
+        with pytest.raises(ValueError):
+            run_batch.safe_join("/data/src", bad)
+    mapping = {f"{i:03d}": {"image_path": f"{i % 3}_c/{i}.jpg", "editing_prompt": "p", "editing_type_id": str(i % 3)} for i in range(10)}
+    ns = lambda **k: argparse.Namespace(image_ids=None, editing_types=None, num_images=None, **k)
+    mute = lambda *a, **k: None
+    assert len(run_batch.select_entries(mapping, ns(), mute)) == 10
+    a = ns()
+    a.editing_types, a.num_images = ["0", "1"], 3
+    sel = run_batch.select_entries(mapping, a, mute)
+    assert [k for k, _ in sel] == ["000", "001", "003"]
+    a = ns()
+    a.image_ids = ["007", "nope", "002"]
+    assert [k for k, _ in run_batch.select_entries(mapping, a, mute)] == ["007", "002"]

@@ -1,0 +1,228 @@
+"""CPU suite (-m "not gpu"): pins the oracle against the golden vectors / known answers this path has, and checks the
+host logic of the product that needs no GPU (schedule tables, tokenizer, weight tables, FLOP model, LoRA fold)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fie_amd  # noqa: F401
+from fie_amd import flops, lcm, presets as P, tokenizer, weights
+from oracle import canny as ocanny
+from oracle import lcm as olcm
+from oracle import metrics as ometrics
+from oracle import nets
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KAT = json.load(open(os.path.join(GOLD, "lcm_known_answers.json")))
+
+
+# ------------------------------------------------------------------ LCM schedule (SURVEY A.5 known answers)
+def test_lcm_timesteps_and_tables_oracle_and_product():
+    o = olcm.LCMOracle()
+    assert o.set_timesteps(4) == KAT["timesteps_4"]
+    p = lcm.LCMSchedule(**P.LCM_SCHED, timestep_spacing="trailing")      # spacing stored, ignored
+    assert p.timesteps(4) == KAT["timesteps_4"]
+    for t, a in KAT["alpha_bar"].items():
+        assert abs(float(o.alphas_cumprod[int(t)]) - a) < 2e-8
+        assert abs(float(p.alphas_cumprod[int(t)]) - a) < 2e-8
+    for t in KAT["c_skip"]:
+        cs, co = o.boundary(int(t))
+        assert abs(cs - KAT["c_skip"][t]) / KAT["c_skip"][t] < 1e-3
+        assert abs(co - KAT["c_out"][t]) < 1e-9
+
+
+@pytest.mark.parametrize("strength,evals", [(1.0, 4), (0.8, 3), (0.5, 2), (0.3, 1), (0.2, 0)])
+def test_strength_to_eval_count(strength, evals):
+    o = olcm.LCMOracle()
+    o.set_timesteps(4)
+    ts, _ = o.get_timesteps(4, strength)
+    plan = lcm.LCMSchedule(**P.LCM_SCHED).plan(4, strength)
+    assert len(ts) == len(plan) == evals == KAT["evals_by_strength"][str(strength)]
+    assert [s["t"] for s in plan] == ts
+    if plan:
+        assert [s["last"] for s in plan] == [False] * (evals - 1) + [True]
+
+
+def test_product_schedule_scalars_match_oracle_step():
+    o = olcm.LCMOracle()
+    o.set_timesteps(4)
+    ts, _ = o.get_timesteps(4, 0.8)
+    plan = lcm.LCMSchedule(**P.LCM_SCHED).plan(4, 0.8)
+    g = torch.Generator().manual_seed(0)
+    x, eps, z = (torch.randn(1, 4, 8, 8, generator=g) for _ in range(3))
+    for st, t in zip(plan, ts):
+        ref, _ = o.step(eps, t, x, None if st["last"] else z)
+        x0 = (x - st["sqrt_1mab"] * eps) / st["sqrt_ab"]
+        den = st["c_out"] * x0 + st["c_skip"] * x
+        mine = den if st["last"] else st["sqrt_ab_prev"] * den + st["sqrt_1mab_prev"] * z
+        assert torch.allclose(mine, ref, atol=1e-5)
+
+
+def test_rng_fixture():
+    g = torch.Generator(device="cpu").manual_seed(42)
+    d = torch.randn((1, 4, 128, 128), generator=g, dtype=torch.float32).flatten()[:4]
+    assert torch.allclose(d, torch.tensor(KAT["rng_seed42_fp32_first4"]), atol=0, rtol=0)
+    g16 = torch.Generator(device="cpu").manual_seed(42)
+    h = torch.randn((1, 4, 128, 128), generator=g16, dtype=torch.float16)
+    assert (h.float().flatten()[:4] - d).abs().max() > 1e-2      # fp16 draws are a different stream
+
+
+def test_timestep_embedding_known_answer():
+    e = nets.timestep_embedding(torch.tensor([499.0]), 320)[0]
+    k = KAT["timestep_embedding_t499_dim320"]
+    assert torch.allclose(e[0:3], torch.tensor(k["0:3"]), atol=1e-5)
+    assert torch.allclose(e[160:163], torch.tensor(k["160:163"]), atol=1e-5)
+
+
+# ------------------------------------------------------------------ CLIP text: pinned by transformers golden vectors
+@pytest.mark.parametrize("tag", ["l", "g"])
+def test_clip_oracle_matches_transformers_golden(tag):
+    z = np.load(os.path.join(GOLD, "clip_text_golden.npz"))
+    sd = {k.split("::", 1)[1]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}_w::")}
+    hidden = sd["text_model.embeddings.position_embedding.weight"].shape[1]
+    cfg = dict(hidden=hidden, layers=max(int(k.split(".")[3]) for k in sd if ".layers." in k) + 1,
+               heads=2 if tag == "l" else 1, act="quick_gelu" if tag == "l" else "gelu",
+               projection_dim=64 if tag == "g" else 0, eps=1e-5, eos_token_id=299)
+    ids = torch.from_numpy(z[f"{tag}_ids"])
+    hs, pooled = nets.clip_text_forward(sd, cfg, ids)
+    assert torch.allclose(hs[-2], torch.from_numpy(z[f"{tag}_penultimate"]), atol=2e-5)
+    assert torch.allclose(pooled, torch.from_numpy(z[f"{tag}_pooled"]), atol=2e-5)
+
+
+def test_clip_oracle_matches_transformers_live():
+    tr = pytest.importorskip("transformers")
+    cfg = tr.CLIPTextConfig(vocab_size=500, hidden_size=128, intermediate_size=256, num_hidden_layers=3,
+                            num_attention_heads=2, max_position_embeddings=77, hidden_act="gelu", projection_dim=32,
+                            eos_token_id=499, pad_token_id=0, bos_token_id=498)
+    torch.manual_seed(3)
+    m = tr.CLIPTextModelWithProjection(cfg).eval()
+    ids = torch.zeros(1, 77, dtype=torch.long)
+    ids[0, :5] = torch.tensor([498, 11, 12, 13, 499])
+    with torch.no_grad():
+        r = m(ids, output_hidden_states=True)
+    mine = dict(hidden=128, layers=3, heads=2, act="gelu", projection_dim=32, eps=1e-5, eos_token_id=499)
+    sd = {(k if k.startswith(("text_model.", "text_projection.")) else "text_model." + k): v for k, v in m.state_dict().items()}
+    hs, pooled = nets.clip_text_forward(sd, mine, ids)
+    assert len(r.hidden_states) == 4 and torch.allclose(hs[-2], r.hidden_states[-2], atol=2e-5)
+    assert torch.allclose(pooled, r.text_embeds, atol=2e-5)
+
+
+# ------------------------------------------------------------------ architecture tables
+@pytest.mark.parametrize("cfg,millions", [(P.UNET_SDXL, 2567.46), (P.CONTROLNET_FULL, 1251.01), (P.VAE_SDXL, 83.65),
+                                          (P.UNET_SSD1B_A1, 1331.33), (P.CLIP_L, 123.06), (P.CLIP_BIGG, 694.66)])
+def test_published_parameter_counts(cfg, millions):
+    assert abs(weights.param_count(cfg) / 1e6 - millions) < 0.01
+
+
+def test_flop_model_matches_survey():
+    assert abs(flops.unet_like_flops(P.UNET_SDXL)["total"] / 1e12 - 6.761) < 2e-3
+    assert abs(flops.unet_like_flops(P.UNET_SSD1B_A)["total"] / 1e12 - 4.268) < 2e-3
+    assert abs(flops.unet_like_flops(P.CONTROLNET_FULL)["total"] / 1e12 - 3.020) < 2e-3
+    v = flops.vae_flops(P.VAE_SDXL)
+    assert abs(v["encode"] / 1e12 - 4.879) < 2e-3 and abs(v["decode"] / 1e12 - 10.470) < 2e-3
+
+
+def test_oracle_graph_consumes_every_parameter():
+    """Every tensor of the tables is read by the oracle graphs (NaN-poison each weight -> output must change)."""
+    cfgs = {k: P.STACKS["tiny"][k2] for k, k2 in (("unet", "unet"), ("controlnet", "controlnet_full"))}
+    sd = weights.synth_state_dict(cfgs["unet"], seed=1)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 8, 8, generator=g)
+    text, pooled = torch.randn(1, 77, 192, generator=g), torch.randn(1, 64, generator=g)
+    tid = torch.tensor([[64., 64., 0, 0, 64., 64.]])
+    used = set()
+
+    class Spy(dict):
+        def __getitem__(self, k):
+            used.add(k)
+            return dict.__getitem__(self, k)
+
+        def get(self, k, d=None):
+            used.add(k)
+            return dict.get(self, k, d)
+
+    nets.unet_forward(Spy(sd), cfgs["unet"], x, 499, text, pooled, tid)
+    assert used >= set(sd), sorted(set(sd) - used)[:5]
+
+
+def test_fold_lora_equals_runtime_adapter():
+    cfg = P.TINY_UNET
+    sd = weights.synth_state_dict(cfg, seed=2)
+    lora = weights.synth_lora(cfg, seed=3, rank=4)
+    name = "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q"
+    w0 = sd[name + ".weight"].clone()
+    n = weights.fold_lora(sd, lora)
+    assert n > 0
+    x = torch.randn(5, w0.shape[1])
+    runtime = x @ w0.T + (x @ lora[name + ".lora_A.weight"].T) @ lora[name + ".lora_B.weight"].T
+    assert torch.allclose(x @ sd[name + ".weight"].T, runtime, atol=1e-5)
+
+
+# ------------------------------------------------------------------ tokenizer, canny, metrics
+def test_standin_tokenizer_shape_and_padding():
+    t1, t2 = tokenizer.StandInTokenizer(49407), tokenizer.StandInTokenizer(0)
+    a, b = t1(["a [rusty] bike", ""]), t2(["a [rusty] bike", ""])
+    assert a.shape == b.shape == (2, 77) and a[0, 0] == 49406 and a[0, 4] == 49407
+    assert a[1, 1] == 49407 and (a[1, 2:] == 49407).all() and (b[1, 2:] == 0).all()
+    assert torch.equal(a[0, :5], b[0, :5])
+    long = t1(" ".join(["w"] * 200))
+    assert long.shape == (1, 77) and long[0, -1] == 49407
+
+
+def test_bpe_tokenizer_with_synthetic_vocab(tmp_path):
+    b2u = tokenizer._bytes_to_unicode()
+    vocab = {c + "</w>": i for i, c in enumerate("abc")}
+    vocab.update({c: 10 + i for i, c in enumerate("abc")})
+    vocab.update({"ab": 20, "ab</w>": 21, "abc</w>": 22})
+    (tmp_path / "vocab.json").write_text(json.dumps(vocab))
+    (tmp_path / "merges.txt").write_text("#version\na b\nab c</w>\na b</w>\n")
+    tk = tokenizer.BpeTokenizer(str(tmp_path / "vocab.json"), str(tmp_path / "merges.txt"), pad_id=0)
+    ids = tk(["abc ab"])[0]
+    assert ids[:4].tolist() == [49406, 22, 21, 49407] and (ids[4:] == 0).all()
+    assert len(b2u) == 256
+
+
+def test_canny_oracle_properties():
+    assert ocanny.rgb_to_gray(np.array([[[255, 255, 255]]], np.uint8))[0, 0] == 255
+    assert ocanny.rgb_to_gray(np.array([[[255, 0, 0]]], np.uint8))[0, 0] == 76
+    flat = np.full((32, 32, 3), 128, np.uint8)
+    assert ocanny.canny_rgb(flat).max() == 0
+    step = flat.copy()
+    step[:, 16:] = 250
+    e = ocanny.canny_rgb(step)
+    assert set(np.unique(e)) == {0, 255} and e[:, 14:18].max() == 255 and e[:, :12].max() == 0 and e[:, 20:].max() == 0
+    assert (e[..., 0] == e[..., 1]).all() and (e[..., 1] == e[..., 2]).all()
+    weak = flat.copy()
+    weak[:, 16:] = 160              # L1 gradient 4*32 = 128: above low (100), below high (200) -> no strong seed
+    assert ocanny.canny_rgb(weak).max() == 0
+    assert np.array_equal(ocanny.canny_rgb(step, 200, 100), e)   # thresholds are swapped when reversed
+
+
+def test_ssim_oracle_and_product_metrics_agree():
+    from PIL import Image
+    from src.metrics import MetricsCalculator
+    rng = np.random.default_rng(0)
+    a = Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8))
+    b = Image.fromarray((np.asarray(a).astype(int) + rng.integers(-20, 20, (64, 64, 3))).clip(0, 255).astype(np.uint8))
+    assert abs(ometrics.ssim(a, a) - 1.0) < 1e-6
+    mc = MetricsCalculator(device="cpu")
+    assert abs(mc.calculate_ssim(a, b) - ometrics.ssim(a, b)) < 1e-6
+    assert abs(mc.calculate_psnr(a, b) - ometrics.psnr(a, b)) < 1e-4
+    m = mc.calculate_all_metrics(a, b, "x")
+    assert set(m) == {"ssim", "lpips", "clip_score", "psnr", "mse", "dino_distance"} and m["lpips"] is None
+
+
+def test_oracle_pipeline_determinism_and_step_count():
+    from PIL import Image
+    from oracle import pipeline as opipe
+    st = P.STACKS["tiny"]
+    cfgs = dict(unet=st["unet"], controlnet=st["controlnet_full"], vae=st["vae"], clip_l=st["clip_l"], clip_g=st["clip_g"])
+    sds = {k: weights.synth_state_dict(cfgs[k], seed=10 + i) for i, k in enumerate(cfgs)}
+    img = Image.fromarray(np.random.default_rng(1).integers(0, 255, (64, 64, 3), dtype=np.uint8))
+    ids = (tokenizer.StandInTokenizer(49407)(["a cat"]), tokenizer.StandInTokenizer(0)(["a cat"]))
+    tr = {}
+    a = opipe.edit(sds, cfgs, img, ids, ids, size=64, seed=7, strength=0.5, guidance_scale=1.0, trace=tr)
+    b = opipe.edit(sds, cfgs, img, ids, ids, size=64, seed=7, strength=0.5, guidance_scale=1.0)
+    assert len(tr["eps"]) == 2 and a.shape == (64, 64, 3) and np.array_equal(a, b)
