@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--strength", type=float, default=0.5)
     ap.add_argument("--guidance", type=float, default=1.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue the launches eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,12 +167,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run = pipe.run_device if args.no_graph else pipe.run_device_graphed
     for s in range(args.warmup):
-        pipe.run_device(jobs[s])
+        run(jobs[s])
     barrier()
     t0 = time.perf_counter()
     for s in range(args.warmup, total):
-        pipe.run_device(jobs[s])
+        run(jobs[s])
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -212,7 +214,7 @@ def main():
             "config": {"workload": f"{args.model} fp16 + ControlNet-Canny({args.controlnet}) LCM img2img, num_inference_steps=4, "
                                    f"strength={args.strength}, guidance={args.guidance}, 1024x1024, batch=1 image per GPU",
                        "unet_preset": cfgs["unet"]["name"], "controlnet_preset": cfgs["controlnet"]["name"],
-                       "unet_evals": evals, "cfg_batch": nb, "parallelism": f"image-parallel x{world}",
+                       "unet_evals": evals, "cfg_batch": nb, "parallelism": f"image-parallel x{world}", "launch": "eager" if args.no_graph else "hipGraph replay",
                        "tflop_per_image": round(fl["total"] / 1e12, 2)},
             "roofline": {"bound": "mfma", "kernel": f"UNet forward ({cfgs['unet']['name']}, batch {nb}): all launches between the "
                                                     "HIP events bracketing unet.encode + unet.decode",

@@ -27,7 +27,7 @@ class ClipText:
         self.proj = Linear(ctx, None, None, w=sd["text_projection.weight"]) if cfg["projection_dim"] else None
         self.act = hip.ACT_QUICK_GELU if cfg["act"] == "quick_gelu" else hip.ACT_GELU
 
-    def __call__(self, ids, eos=None):
+    def __call__(self, ids, eos_rows=None):
         """ids: int tensor [B, T] (host or device).  Returns (penultimate [B*T, C] f16, pooled [B, P] f16 or None)."""
         ctx, cfg = self.ctx, self.cfg
         b, t = ids.shape
@@ -50,8 +50,8 @@ class ClipText:
         pooled = None
         if self.proj is not None:
             last = ctx.layernorm(x, self.final_ln.g, self.final_ln.b, cfg["eps"])
-            if eos is None:                                                       # first EOS (host index logic)
+            if eos_rows is None:                                                  # first EOS (host index logic)
                 eos = (ids.to("cpu") == cfg["eos_token_id"]).int().argmax(dim=-1)
-            rows = (torch.arange(b) * t + eos).to(ctx.device)
-            pooled = self.proj(ctx, last.index_select(0, rows))
+                eos_rows = (torch.arange(b) * t + eos).to(ctx.device)
+            pooled = self.proj(ctx, last.index_select(0, eos_rows))
         return penult, pooled

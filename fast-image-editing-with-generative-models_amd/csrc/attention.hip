@@ -205,6 +205,241 @@ int launch_attn(fie_ctx* ctx, const AttnArgs& a, int B) {
     return FIE_OK;
 }
 
+
+// =====================================================================================================================
+// v2: same data flow, restructured around the two costs the profile showed (VALU-bound softmax, unpipelined staging):
+//   * K/V tiles arrive by LDS-DMA into a 2-stage ring (prefetch of tile t+1 overlaps tile t; one barrier per tile)
+//   * Q is pre-scaled by scale*log2(e); the score accumulators start at -m_ref so exp2 needs no subtraction; the
+//     running reference only moves when a row max grows by more than 2^6 (deferred rescale) or on the first tile
+//   * masks are applied only on boundary tiles; max via v_max3 + permlane swaps; P packed with v_cvt_pkrtz and its row
+//     sum taken from the packed fp16 values with v_dot2 (numerator and denominator see the same rounding)
+__device__ __attribute__((aligned(64))) half_t g_attn_zero[512];
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max2f(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float xor16_32_max(float x) {
+    x = max2f(x, __shfl_xor(x, 16));
+    return max2f(x, __shfl_xor(x, 32));
+}
+__device__ __forceinline__ float xor16_32_sum(float x) {
+    x += __shfl_xor(x, 16);
+    return x + __shfl_xor(x, 32);
+}
+
+template <int D, int QF, int KT>
+__global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
+    constexpr int KF = KT / 16, DK = D / 32, DF = D / 16, PS = KT / 32;
+    constexpr int CH = D / 8;                  // 16-byte chunks per row
+    constexpr int RP = 64 / CH > 0 ? 64 / CH : 1;   // rows per 1-KiB LDS-DMA piece (8 for D=64, 1 for D=512)
+    constexpr int PPR = CH / 64 > 0 ? CH / 64 : 1;  // pieces per row (1)
+    static_assert(PPR == 1, "row longer than one LDS-DMA piece");
+    constexpr int NPT = KT / RP;               // pieces per K (or V) tile
+    constexpr int PW = 2 * NPT / 4;            // pieces per wave per tile (K and V)
+    constexpr int TILE = KT * D;               // halfs
+    constexpr float THR = 6.0f;
+    extern __shared__ __attribute__((aligned(16))) half_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (64 * QF) + wave * (16 * QF);
+
+    const half_t* Qb = p.Q + (int64_t)b * p.Tq * p.ldq + h * D;
+    const half_t* Kb = p.K + (int64_t)b * p.Tk * p.ldk + h * D;
+    const half_t* Vb = p.V + (int64_t)b * p.Tk * p.ldv + h * D;
+
+    // LDS-DMA source mapping of this lane inside a piece
+    const int prow = lane / CH, pphys = lane % CH;
+
+    auto issue = [&](int t, int stage) {
+        half_t* sk = smem + stage * 2 * TILE;
+        half_t* sv = sk + TILE;
+        const int key0 = t * KT;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int pc = wave + 4 * i;                       // 0 .. 2*NPT-1: first NPT pieces = K, rest = V
+            const bool isv = pc >= NPT;
+            const int pr = isv ? pc - NPT : pc;
+            const int row = pr * RP + prow;
+            const int key = key0 + row;
+            const int chunk = pphys ^ (row & 7);
+            const half_t* src = isv ? Vb + (int64_t)key * p.ldv + chunk * 8 : Kb + (int64_t)key * p.ldk + chunk * 8;
+            if (key >= p.Tk) src = g_attn_zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)((isv ? sv : sk) + pr * 512), 16, 0, 0);
+        }
+    };
+
+    int kend = p.Tk;
+    if (p.causal) kend = min(kend, min(p.Tq, (int)(blockIdx.x + 1) * 64 * QF));
+    const int ntiles = (kend + KT - 1) / KT;
+    issue(0, 0);
+
+    // Q fragments, pre-scaled so that scores are already in the log2 domain
+    f16x8 qf_[QF][DK];
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        const int q = q0 + a * 16 + fr;
+#pragma unroll
+        for (int kk = 0; kk < DK; ++kk) {
+            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (q < p.Tq) v = *reinterpret_cast<const f16x8*>(Qb + (int64_t)q * p.ldq + kk * 32 + fq * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] * p.scale_log2);
+            qf_[a][kk] = v;
+        }
+    }
+
+    f32x4 o[QF][DF];
+    float mref[QF], lrun[QF];
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        mref[a] = 0.f;
+        lrun[a] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) o[a][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const f16x2 ones = {(half_t)1.f, (half_t)1.f};
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * KT;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // tile t landed; tile t-1 fully consumed
+        if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
+        const half_t* sk = smem + (t & 1) * 2 * TILE;
+        const half_t* sv = sk + TILE;
+
+        f32x4 s[QF][KF];
+#pragma unroll
+        for (int a = 0; a < QF; ++a)
+#pragma unroll
+            for (int f = 0; f < KF; ++f) s[a][f] = (f32x4){-mref[a], -mref[a], -mref[a], -mref[a]};
+#pragma unroll
+        for (int kk = 0; kk < DK; ++kk) {
+#pragma unroll
+            for (int f = 0; f < KF; ++f) {
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + kv_off<D>(f * 16 + fr, kk * 4 + fq));
+#pragma unroll
+                for (int a = 0; a < QF; ++a)
+                    s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf_[a][kk], s[a][f], 0, 0, 0);
+            }
+        }
+
+        const bool edge = (key0 + KT > p.Tk) || (p.causal && key0 + KT > q0);     // wave-uniform
+        f16x8 pf[QF][PS];
+#pragma unroll
+        for (int a = 0; a < QF; ++a) {
+            if (edge) {
+                const int q = q0 + a * 16 + fr;
+#pragma unroll
+                for (int f = 0; f < KF; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + f * 16 + fq * 4 + r;
+                        if (key >= p.Tk || (p.causal && key > q)) s[a][f][r] = -1e30f;
+                    }
+            }
+            float mx = max3f(s[a][0][0], s[a][0][1], s[a][0][2]);
+            mx = max2f(mx, s[a][0][3]);
+#pragma unroll
+            for (int f = 1; f < KF; ++f) {
+                mx = max3f(mx, s[a][f][0], s[a][f][1]);
+                mx = max3f(mx, s[a][f][2], s[a][f][3]);
+            }
+            mx = xor16_32_max(mx);
+            if (t == 0 || __any(mx > THR)) {
+                // move the reference: rows whose max grew (or every row on the first tile) are re-based
+                const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                mref[a] += delta;
+                lrun[a] *= alpha;
+#pragma unroll
+                for (int d = 0; d < DF; ++d) o[a][d] *= alpha;
+#pragma unroll
+                for (int f = 0; f < KF; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[a][f][r] -= delta;
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int f = 0; f < KF; ++f) {
+                const auto lo = __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(s[a][f][0]), __builtin_amdgcn_exp2f(s[a][f][1]));
+                const auto hi = __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(s[a][f][2]), __builtin_amdgcn_exp2f(s[a][f][3]));
+                const f16x2 l2 = __builtin_bit_cast(f16x2, lo), h2 = __builtin_bit_cast(f16x2, hi);
+                sum = __builtin_amdgcn_fdot2(l2, ones, sum, false);
+                sum = __builtin_amdgcn_fdot2(h2, ones, sum, false);
+                pf[a][f >> 1][(f & 1) * 4 + 0] = l2[0];
+                pf[a][f >> 1][(f & 1) * 4 + 1] = l2[1];
+                pf[a][f >> 1][(f & 1) * 4 + 2] = h2[0];
+                pf[a][f >> 1][(f & 1) * 4 + 3] = h2[1];
+            }
+            lrun[a] += sum;
+        }
+
+        const int trow = fq * 4 + (fr >> 2);
+        const int tsub = (lane & 1) * 4;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) {
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+                const int ra = ps * 32 + trow, rb = ra + 16;
+                const int ch = d * 2 + ((lane & 3) >> 1);
+                const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(sv + kv_off<D>(ra, ch) + tsub));
+                const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(sv + kv_off<D>(rb, ch) + tsub));
+                union { struct { s16x4 lo, hi; } s; f16x8 v; } u;
+                u.s.lo = va;
+                u.s.hi = vb;
+#pragma unroll
+                for (int a = 0; a < QF; ++a)
+                    o[a][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pf[a][ps], o[a][d], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        const float l = xor16_32_sum(lrun[a]);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        const int q = q0 + a * 16 + fr;
+        if (q >= p.Tq) continue;
+        half_t* orow = p.O + ((int64_t)b * p.Tq + q) * p.ldo + h * D;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) {
+            f16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (half_t)(o[a][d][r] * inv);
+            *reinterpret_cast<f16x4*>(orow + d * 16 + fq * 4) = v;
+        }
+    }
+}
+
+template <int D, int QF, int KT>
+int launch_attn2(fie_ctx* ctx, const AttnArgs& a, int B) {
+    const size_t lds = (size_t)4 * KT * D * sizeof(half_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<D, QF, KT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((a.Tq + 64 * QF - 1) / (64 * QF)), (unsigned)a.H, (unsigned)B), block(256);
+    hipLaunchKernelGGL((attn2_kernel<D, QF, KT>), grid, block, lds, ctx->stream, a);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+int g_attn_variant = 0;   // tuning hook: 0 = v2 (LDS-DMA ring, deferred rescale), 1 = v1
+
 }  // namespace
 
 extern "C" int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V,
@@ -220,8 +455,18 @@ extern "C" int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const
     a.Q = (const half_t*)Q; a.ldq = ldq; a.K = (const half_t*)K; a.ldk = ldk; a.V = (const half_t*)V; a.ldv = ldv;
     a.O = (half_t*)O; a.ldo = ldo; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
     a.scale_log2 = scale * 1.4426950408889634f;
-    if (D == 512) return launch_attn<512, 1, 32>(ctx, a, B);
     const int64_t blocks128 = (int64_t)((Tq + 127) / 128) * H * B;
-    if (blocks128 >= ctx->num_cus * 2) return launch_attn<64, 2, 64>(ctx, a, B);
-    return launch_attn<64, 1, 64>(ctx, a, B);
+    if (g_attn_variant == 1) {
+        if (D == 512) return launch_attn<512, 1, 32>(ctx, a, B);
+        if (blocks128 >= ctx->num_cus * 2) return launch_attn<64, 2, 64>(ctx, a, B);
+        return launch_attn<64, 1, 64>(ctx, a, B);
+    }
+    if (D == 512) return launch_attn2<512, 1, 32>(ctx, a, B);
+    if (blocks128 >= ctx->num_cus * 2) return launch_attn2<64, 2, 64>(ctx, a, B);
+    return launch_attn2<64, 1, 64>(ctx, a, B);
+}
+
+extern "C" int fie_debug_attn_variant(int v) {
+    g_attn_variant = v;
+    return FIE_OK;
 }

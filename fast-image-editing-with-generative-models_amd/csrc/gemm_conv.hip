@@ -35,6 +35,59 @@ struct GemmArgs {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
 
+template <int FM, int FN, int WM, int WN>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    // ---- epilogue: lane holds C[m = .. + fr][n = .. + fq*4 + (0..3)]
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = m0 + wm * WM + j * 16 + fr;
+        if (m >= p.M) continue;
+        const half_t* rb = nullptr;
+        if (p.rowbias) rb = p.rowbias + (int64_t)(m / p.rows_per_batch) * p.ld_rowbias;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int n = n0 + wn * WN + i * 16 + fq * 4;
+            if (n >= p.N) continue;
+            f32x4 v = acc[i][j];
+            if (p.bias) {
+                const f16x4 b = *reinterpret_cast<const f16x4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+            }
+            if (rb) {
+                const f16x4 b = *reinterpret_cast<const f16x4*>(rb + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+            }
+            if (p.act == FIE_ACT_GEGLU) {
+                f16x2 o;
+                o[0] = (half_t)(v[0] * fie_gelu(v[1]) * p.scale);
+                o[1] = (half_t)(v[2] * fie_gelu(v[3]) * p.scale);
+                *reinterpret_cast<f16x2*>(p.C + (int64_t)m * p.ldc + (n >> 1)) = o;
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = v[r];
+                if (p.act == FIE_ACT_SILU) x = fie_silu(x);
+                else if (p.act == FIE_ACT_GELU) x = fie_gelu(x);
+                else if (p.act == FIE_ACT_QUICK_GELU) x = fie_qgelu(x);
+                v[r] = x * p.scale;
+            }
+            if (p.res) {
+                const f16x4 b = *reinterpret_cast<const f16x4*>(p.res + (int64_t)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+            }
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+            *reinterpret_cast<f16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+        }
+    }
+}
+
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     constexpr int WM = BM / 2, WN = BN / 2;
@@ -160,70 +213,262 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds C[m = .. + fr][n = .. + fq*4 + (0..3)]
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const int m = m0 + wm * WM + j * 16 + fr;
-        if (m >= p.M) continue;
-        const half_t* rb = nullptr;
-        if (p.rowbias) rb = p.rowbias + (int64_t)(m / p.rows_per_batch) * p.ld_rowbias;
-#pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            const int n = n0 + wn * WN + i * 16 + fq * 4;
-            if (n >= p.N) continue;
-            f32x4 v = acc[i][j];
-            if (p.bias) {
-                const f16x4 b = *reinterpret_cast<const f16x4*>(p.bias + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
-            }
-            if (rb) {
-                const f16x4 b = *reinterpret_cast<const f16x4*>(rb + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
-            }
-            if (p.act == FIE_ACT_GEGLU) {
-                f16x2 o;
-                o[0] = (half_t)(v[0] * fie_gelu(v[1]) * p.scale);
-                o[1] = (half_t)(v[2] * fie_gelu(v[3]) * p.scale);
-                *reinterpret_cast<f16x2*>(p.C + (int64_t)m * p.ldc + (n >> 1)) = o;
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = v[r];
-                if (p.act == FIE_ACT_SILU) x = fie_silu(x);
-                else if (p.act == FIE_ACT_GELU) x = fie_gelu(x);
-                else if (p.act == FIE_ACT_QUICK_GELU) x = fie_qgelu(x);
-                v[r] = x * p.scale;
-            }
-            if (p.res) {
-                const f16x4 b = *reinterpret_cast<const f16x4*>(p.res + (int64_t)m * p.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
-            }
-            f16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-            *reinterpret_cast<f16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
-        }
-    }
+    epilogue<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+
+// =====================================================================================================================
+// v2 mainloop: ST-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4), counted vmcnt + one raw s_barrier per
+// K-step.  A wave-instruction writes 1 KiB linearly = 8 tile rows x 128 B, so the XOR swizzle is applied to the per-lane
+// SOURCE chunk (lane l fetches logical chunk (l&7)^(l>>3) of row l>>3) and again on the fragment reads.  Out-of-range
+// im2col / M / K lanes fetch from a zero page.  MODE 0 = GEMM, 1 = generic conv, 2 = conv with Cin % 64 == 0 (tap-major
+// K-steps: per-row gather state is recomputed only when the tap changes).
+__device__ __attribute__((aligned(64))) half_t g_zero_page[64];
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+    else static_assert(N < 0, "add the vmcnt literal");
+}
+
+__device__ __forceinline__ void glds16(const half_t* src, half_t* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int BM, int BN, int ST, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs p) {
+    constexpr int WGN = NW / 2;                        // waves: 2 along m x NW/2 along n
+    constexpr int WM = BM / 2, WN = BN / WGN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int RA = BM / (8 * NW), RW = BN / (8 * NW);  // LDS-DMA pieces (8 rows x 128 B) per wave per stage
+    constexpr int NP = RA + RW;
+    constexpr int STAGE = (BM + BN) * BK;              // halfs per stage
+    extern __shared__ __attribute__((aligned(16))) half_t smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / p.nbn) * BM;
+    const int n0 = (bid % p.nbn) * BN;
+
+    const int lr = lane >> 3;                          // row inside a piece
+    const int c8 = (lane & 7) ^ lr;                    // logical 16-byte chunk this lane fetches (source-side swizzle)
+
+    // ---- per-thread A-row descriptors: piece i of this wave covers tile rows (wave + NW i) * 8 .. + 7
+    int64_t a_base[RA];
+    int a_ih[RA], a_iw[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + (wave + NW * i) * 8 + lr;
+        a_ok[i] = m < p.M;
+        if (MODE != 0) {
+            const int hw = p.OH * p.OW;
+            const int b = m / hw, rem = m - b * hw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            a_ih[i] = oh * p.stride - p.pt;
+            a_iw[i] = ow * p.stride - p.pl;
+            a_base[i] = (int64_t)b * p.H * p.W * p.Cin;
+        } else {
+            a_base[i] = (int64_t)m;
+            a_ih[i] = a_iw[i] = 0;
+        }
+    }
+    const half_t* w_src[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) w_src[i] = p.Wt + (int64_t)(n0 + (wave + NW * i) * 8 + lr) * p.ldw + c8 * 8;
+
+    // gather state
+    int tap = 0, ci = c8 * 8;                          // MODE 1
+    if (MODE == 1) {
+        while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+    }
+    int cs = 0, ftap = 0;                              // MODE 2: channel step inside the tap, current tap
+    const int csteps = MODE == 2 ? p.Cin / BK : 1;
+    int64_t t_off[RA];                                 // MODE 2: element offset of (row, tap) incl. this lane's chunk
+    bool t_ok[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) { t_off[i] = 0; t_ok[i] = false; }
+
+    auto issue = [&](int kt, int stage) {
+        half_t* sa = smem + stage * STAGE;
+        half_t* sw = sa + BM * BK;
+        if (MODE == 2) {
+            if (cs == 0) {
+                const int ky = (ftap * 11) >> 5, kx = ftap - 3 * ky;
+                const int hlim = p.H << p.ups, wlim = p.W << p.ups;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const int ih = a_ih[i] + ky, iw = a_iw[i] + kx;
+                    t_ok[i] = a_ok[i] && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+                    t_off[i] = a_base[i] + ((int64_t)((ih >> p.ups) * p.W + (iw >> p.ups))) * p.Cin + c8 * 8;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                glds16(t_ok[i] ? p.A1 + t_off[i] + cs * BK : g_zero_page, sa + (wave + NW * i) * 512);
+            if (++cs == csteps) { cs = 0; ++ftap; }
+        } else if (MODE == 1) {
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+            const int hlim = p.H << p.ups, wlim = p.W << p.ups;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int ih = a_ih[i] + ky, iw = a_iw[i] + kx;
+                const bool ok = a_ok[i] && tap < 9 && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+                const int64_t off = a_base[i] + ((int64_t)((ih >> p.ups) * p.W + (iw >> p.ups))) * p.Cin + ci;
+                glds16(ok ? p.A1 + off : g_zero_page, sa + (wave + NW * i) * 512);
+            }
+            ci += BK;
+            while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
+        } else {
+            const int k = kt * BK + c8 * 8;
+            const bool k1 = k < p.K1;
+            const half_t* src = k1 ? p.A1 : p.A2;
+            const int64_t ld = k1 ? p.lda1 : p.lda2;
+            const int kk = k1 ? k : k - p.K1;
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                glds16((a_ok[i] && k < p.K) ? src + a_base[i] * ld + kk : g_zero_page, sa + (wave + NW * i) * 512);
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) glds16(w_src[i] + kt * BK, sw + (wave + NW * i) * 512);
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s)
+        if (s < nk) issue(s, s);
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int stage = 0, fill = ST - 1;                      // stage being consumed, stage to refill
+    for (int kt = 0; kt < nk; ++kt) {
+        // groups still allowed in flight: the ones issued after stage kt's
+        const int later = min(kt + ST - 2, nk - 1) - kt;
+        if (ST >= 4 && later == 2) wait_vm_barrier<2 * NP>();
+        else if (ST >= 3 && later >= 1) wait_vm_barrier<NP>();
+        else wait_vm_barrier<0>();
+        if (kt + ST - 1 < nk) issue(kt + ST - 1, fill);
+        const half_t* sa = smem + stage * STAGE;
+        const half_t* sw = sa + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 fw[FN], fa[FM];
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+                fw[i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * WN + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+                fa[j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + j * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+        stage = stage + 1 == ST ? 0 : stage + 1;
+        fill = fill + 1 == ST ? 0 : fill + 1;
+    }
+    epilogue<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int BM, int BN, int ST, int MODE, int NW = 4>
+void launch2_t(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
+    constexpr int lds = ST * (BM + BN) * BK * (int)sizeof(half_t);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, BN, ST, MODE, NW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm2_kernel<BM, BN, ST, MODE, NW>), grid, dim3(NW * 64), lds, ctx->stream, a);
+}
+
+int g_force_tile = 0;   // tuning hook (fie_debug_force_tile): 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64
+
+// tile codes: 1 = 128x128, 2 = 128x64, 3 = 64x64 (v1 register-staged kernel); 11/12/13 = v2 LDS-DMA ring, 3 stages;
+// 21/22/23 = v2, 4 stages (128x128 has no 4-stage build: 128 KiB)
 template <int MODE>
 int launch(fie_ctx* ctx, GemmArgs& a) {
     auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-    const int64_t want = (int64_t)ctx->num_cus * 3 / 2;
-    int bm, bn;
-    if (blocks(128, 128) >= want) { bm = 128; bn = 128; }
-    else if (blocks(128, 64) >= want) { bm = 128; bn = 64; }
-    else { bm = 64; bn = 64; }
+    // variant choice from tools/microbench.py on MI355X (profiles/r01_microbench.md): the LDS-DMA ring wins where a CU holds
+    // >= 2 blocks (128x64 x3 stages for convs, 64x64 x3 stages for small grids); large GEMM grids keep the register-staged
+    // 2-blocks-per-CU kernel
+    const int64_t cus = ctx->num_cus;
+    int code;
+    if (MODE == 1) {
+        code = a.Cin % BK == 0 ? 12 : 2;
+    } else if (a.N >= 2048 && a.K >= 1024 && blocks(128, 128) >= cus) {
+        code = 1;
+    } else if (blocks(128, 64) >= cus * 7 / 2) {
+        code = 2;
+    } else {
+        code = 13;
+    }
+    if (g_force_tile) code = g_force_tile;
+    const int tile = code % 10, ver = code / 10;
+    const int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
+    FIE_REQUIRE(ver <= 3 && tile >= 1 && tile <= 3 && !(ver == 3 && tile == 3), "bad tile code %d", code);
     a.nbm = (a.M + bm - 1) / bm;
     a.nbn = (a.N + bn - 1) / bn;
     const dim3 grid((unsigned)(a.nbm * a.nbn)), block(256);
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((gemm_kernel<128, 128, MODE>), grid, block, 0, ctx->stream, a);
-    else if (bm == 128) hipLaunchKernelGGL((gemm_kernel<128, 64, MODE>), grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL((gemm_kernel<64, 64, MODE>), grid, block, 0, ctx->stream, a);
+    constexpr int M2 = MODE;     // v2 conv: fast path when a K-step never straddles a tap
+    const bool fast = MODE == 1 && a.Cin % BK == 0;
+    if (ver == 0) {
+        if (tile == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, MODE>), grid, block, 0, ctx->stream, a);
+        else if (tile == 2) hipLaunchKernelGGL((gemm_kernel<128, 64, MODE>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((gemm_kernel<64, 64, MODE>), grid, block, 0, ctx->stream, a);
+    } else if (ver == 1) {
+        if (fast) {
+            if (tile == 1) launch2_t<128, 128, 3, 2>(ctx, a, grid);
+            else if (tile == 2) launch2_t<128, 64, 3, 2>(ctx, a, grid);
+            else launch2_t<64, 64, 3, 2>(ctx, a, grid);
+        } else {
+            if (tile == 1) launch2_t<128, 128, 3, M2>(ctx, a, grid);
+            else if (tile == 2) launch2_t<128, 64, 3, M2>(ctx, a, grid);
+            else launch2_t<64, 64, 3, M2>(ctx, a, grid);
+        }
+    } else if (ver == 3) {          // 8 waves per block: two waves per SIMD inside ONE block (for grids of <= 1 block per CU)
+        if (fast) {
+            if (tile == 1) launch2_t<128, 128, 3, 2, 8>(ctx, a, grid);
+            else launch2_t<128, 64, 3, 2, 8>(ctx, a, grid);
+        } else {
+            if (tile == 1) launch2_t<128, 128, 3, M2, 8>(ctx, a, grid);
+            else launch2_t<128, 64, 3, M2, 8>(ctx, a, grid);
+        }
+    } else {
+        if (fast) {
+            if (tile == 1) launch2_t<128, 128, 3, 2>(ctx, a, grid);
+            else if (tile == 2) launch2_t<128, 64, 4, 2>(ctx, a, grid);
+            else launch2_t<64, 64, 4, 2>(ctx, a, grid);
+        } else {
+            if (tile == 1) launch2_t<128, 128, 3, M2>(ctx, a, grid);
+            else if (tile == 2) launch2_t<128, 64, 4, M2>(ctx, a, grid);
+            else launch2_t<64, 64, 4, M2>(ctx, a, grid);
+        }
+    }
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -266,6 +511,11 @@ __global__ void pack_conv_kernel(const half_t* src, int Cout, int Cin, int cin_p
 }  // namespace
 
 extern "C" {
+
+int fie_debug_force_tile(int t) {
+    g_force_tile = t;
+    return FIE_OK;
+}
 
 int fie_gemm_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2,
                  const void* Wpacked, int64_t ldw, void* C, int64_t ldc, int M, int N, int K, const void* bias,

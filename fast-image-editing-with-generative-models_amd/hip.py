@@ -39,6 +39,8 @@ SIGNATURES = {
     "fie_pack_rows_f16": [_P, _P, _L, _I, _I, _P, _L, _I, _I],
     "fie_pack_conv3x3_f16": [_P, _P, _I, _I, _I, _P, _L, _I],
     "fie_canny_rgb_u8": [_P, _I, _I, _I, _I, _P],
+    "fie_debug_force_tile": [_I],
+    "fie_debug_attn_variant": [_I],
 }
 
 _lib = None

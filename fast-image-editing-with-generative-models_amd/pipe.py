@@ -2,6 +2,7 @@
 StableDiffusionXLControlNetImg2ImgPipeline call at /root/reference/src/pipeline.py:261-272, but every stage
 (CLIP text, VAE encode, ControlNet + UNet evaluations, CFG + LCM step, VAE decode, pixel conversion) runs in the
 hand-written HIP kernels of csrc/ (call order: SURVEY.md 3.2 steps 1-9)."""
+import os
 import types
 
 import numpy as np
@@ -35,6 +36,8 @@ class HipImg2ImgPipeline:
         self.progress = {}
         self.last_stats = {}
         self.timing = None         # set to [] to collect per-stage HIP-event timings in run_device()
+        self.use_graph = os.environ.get("FIE_NO_GRAPH", "0") != "1"
+        self._graphs = {}
 
     # -- diffusers API surface the reference touches
     def set_progress_bar_config(self, **kw):          # run_batch.py:157-158
@@ -80,11 +83,16 @@ class HipImg2ImgPipeline:
         lh, lw = h // 8, w // 8
         u8 = lambda im: torch.from_numpy(np.array(im.convert("RGB"))).to(dev)
         n_noise = 2 + sum(1 for st in steps if not st["last"])
+        nb = 2 if do_cfg else 1
+        ids_g = self.tok_g(texts)
+        eos = (ids_g == self.cfgs["clip_g"]["eos_token_id"]).int().argmax(dim=-1)       # first EOS per row
         return dict(
-            ids_l=self.tok_l(texts).to(dev, torch.int32), ids_g=self.tok_g(texts).to(dev, torch.int32),
-            eos_g=(self.tok_g(texts) == self.cfgs["clip_g"]["eos_token_id"]).int().argmax(dim=-1),
-            img_u8=u8(image), ctl_u8=u8(control_image), hw=(h, w), steps=steps, nb=2 if do_cfg else 1,
+            ids_l=self.tok_l(texts).to(dev, torch.int32), ids_g=ids_g.to(dev, torch.int32),
+            eos_rows=(torch.arange(nb) * ids_g.shape[1] + eos).to(dev),
+            img_u8=u8(image), ctl_u8=u8(control_image), hw=(h, w), steps=steps, nb=nb,
             guidance=float(guidance_scale), cn_scale=float(controlnet_conditioning_scale),
+            time_ids=torch.tensor([[h, w, 0, 0, h, w]], dtype=torch.float32).repeat(nb, 1).to(dev),
+            t_dev=[torch.full((nb, 1), float(st["t"]), dtype=torch.float32).to(dev) for st in steps],
             noises=[self._randn((1, 4, lh, lw), generator) for _ in range(n_noise)])
 
     def _mark(self, name):
@@ -104,7 +112,7 @@ class HipImg2ImgPipeline:
         self._mark("start")
         # 1-2. text encoders (negative prompt "" is really encoded: SURVEY 0 item 4)
         pl, _ = self.clip_l(job["ids_l"])
-        pg, pooled = self.clip_g(job["ids_g"], eos=job["eos_g"])
+        pg, pooled = self.clip_g(job["ids_g"], eos_rows=job["eos_rows"])
         text = torch.cat([pl, pg], dim=1)
         text_len = text.shape[0] // nb
         self._mark("clip")
@@ -121,15 +129,13 @@ class HipImg2ImgPipeline:
                         latents, model_in)
         self._mark("vae_encode")
         # 6. per-image invariants
-        time_ids = torch.tensor([[h, w, 0, 0, h, w]], dtype=torch.float32, device=dev).repeat(nb, 1)
-        self.unet.begin_image(pooled, time_ids)
-        self.controlnet.begin_image(pooled, time_ids)
+        self.unet.begin_image(pooled, job["time_ids"])
+        self.controlnet.begin_image(pooled, job["time_ids"])
         cond_emb = self.controlnet.cond_embedding(cond)
         decode_in = torch.empty((1, lh, lw, 8), device=dev, dtype=F16)
         self._mark("cond_embed")
         # 7. denoising loop
-        for st in steps:
-            t_dev = torch.full((nb, 1), float(st["t"]), device=dev, dtype=torch.float32)
+        for st, t_dev in zip(steps, job["t_dev"]):
             tb_u = self.unet.time_rowbias(t_dev)
             tb_c = self.controlnet.time_rowbias(t_dev)
             self._mark("embed")
@@ -152,6 +158,37 @@ class HipImg2ImgPipeline:
         self._latents = latents
         return out_u8
 
+    _TENSOR_KEYS = ("ids_l", "ids_g", "eos_rows", "img_u8", "ctl_u8", "time_ids")
+
+    def run_device_graphed(self, job):
+        """run_device() replayed from a hipGraph: the ~2 500 launches of one edit are captured once per
+        (size, CFG batch, step plan, scales) and replayed with the job's inputs copied into the graph's static buffers.
+        The returned u8 image is the graph's static output buffer (consume it before the next replay)."""
+        key = (job["hw"], job["nb"], tuple(st["t"] for st in job["steps"]), job["guidance"], job["cn_scale"])
+        entry = self._graphs.get(key)
+        if entry is None:
+            static = dict(job)
+            for k in self._TENSOR_KEYS:
+                static[k] = job[k].clone()
+            static["noises"] = [n.clone() for n in job["noises"]]
+            static["t_dev"] = [t.clone() for t in job["t_dev"]]
+            timing, self.timing = self.timing, None
+            self.run_device(static)                     # eager warm-up: lazy workspaces / function attributes
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.run_device(static)
+            self.timing = timing
+            entry = self._graphs[key] = (graph, static, out)
+        graph, static, out = entry
+        if static is not job:
+            for k in self._TENSOR_KEYS:
+                static[k].copy_(job[k], non_blocking=True)
+            for d, s_ in zip(static["noises"], job["noises"]):
+                d.copy_(s_, non_blocking=True)
+        graph.replay()
+        return out
+
     def stage_ms(self):
         """Per-stage device milliseconds of the last run_device() (needs `self.timing = []` before the call)."""
         torch.cuda.synchronize()
@@ -165,7 +202,7 @@ class HipImg2ImgPipeline:
                  output_type="pil", **unused):
         job = self.prepare(prompt, negative_prompt, image, control_image, strength, num_inference_steps,
                            guidance_scale, controlnet_conditioning_scale, generator)
-        out_u8 = self.run_device(job)
+        out_u8 = self.run_device_graphed(job) if self.use_graph else self.run_device(job)
         if output_type == "latent":
             lh, lw = self.last_stats["latent_hw"]
             return types.SimpleNamespace(images=[self._latents.view(lh, lw, 4).clone()])

@@ -131,6 +131,11 @@ int fie_pack_rows_f16(fie_ctx* ctx, const void* src, int64_t ld_src, int N, int 
 int fie_pack_conv3x3_f16(fie_ctx* ctx, const void* src_oihw, int Cout, int Cin, int cin_pad, void* dst,
                          int64_t ldw, int Npad);
 
+/* ---- tuning hook for micro-benchmarks: force the GEMM/conv tile (0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64).
+ * Process-global; not part of the drop-in surface. */
+int fie_debug_force_tile(int tile);
+int fie_debug_attn_variant(int variant);   /* 0 = default kernel, 1 = first-generation kernel (A/B benchmarking) */
+
 /* ---- K11 Canny on the host (integer exact).  Replaces cv2.cvtColor(RGB2GRAY) + cv2.Canny at
  * src/pipeline.py:200,205 and the 3-channel stack at :208.  rgb, edges_rgb: host u8 [H, W, 3]. */
 int fie_canny_rgb_u8(const uint8_t* rgb, int H, int W, int low, int high, uint8_t* edges_rgb);

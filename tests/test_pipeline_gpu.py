@@ -149,3 +149,22 @@ def test_editor_api_surface(fie):
     with pytest.raises(ValueError):
         ed.edit(img, "x", strength=1.5)
     ed.clear_memory()
+
+
+def test_graph_replay_matches_eager(rig):
+    """The captured hipGraph replays the same launches: bit-identical output, also after swapping inputs."""
+    from oracle import canny
+    cfgs, sds32, pipe = rig
+    outs = {}
+    for mode in (False, True):
+        pipe.use_graph = mode
+        for seed in (21, 22):
+            img = synth_image(seed, 128)
+            ctrl = Image.fromarray(canny.canny_rgb(np.asarray(img)))
+            outs[(mode, seed)] = np.asarray(pipe(prompt=f"a [green] shape {seed}", negative_prompt="", image=img,
+                                                 control_image=ctrl, strength=0.8, num_inference_steps=4, guidance_scale=1.5,
+                                                 controlnet_conditioning_scale=0.5,
+                                                 generator=torch.Generator("cpu").manual_seed(seed)).images[0])
+    pipe.use_graph = True
+    assert np.array_equal(outs[(False, 21)], outs[(True, 21)]) and np.array_equal(outs[(False, 22)], outs[(True, 22)])
+    assert not np.array_equal(outs[(True, 21)], outs[(True, 22)])

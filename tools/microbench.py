@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Per-shape kernel micro-benchmark on the GPU box (HIP-event timed, random data): TFLOP/s of the GEMM / conv /
+attention shapes that make up the SSD-1B + ControlNet + VAE hot path.  usage: tools/microbench.py [gemm|conv|attn|all] [tiles]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fie_amd  # noqa: E402,F401
+from fie_amd import hip  # noqa: E402
+
+ctx = hip.context(0)
+DEV = "cuda"
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+GEMMS = [(8192, 1920, 640), (8192, 640, 640), (8192, 5120, 640), (8192, 640, 2560),
+         (2048, 3840, 1280), (2048, 1280, 1280), (2048, 10240, 1280), (2048, 1280, 5120),
+         (154, 2560, 2048), (32768, 320, 320), (16384, 1536, 512), (4096, 4096, 4096)]
+CONVS = [  # b, h, w, cin, cout, stride, ups
+    (2, 128, 128, 320, 320, 1, 0), (2, 128, 128, 640, 320, 1, 0), (2, 64, 64, 640, 640, 1, 0), (2, 64, 64, 1280, 640, 1, 0),
+    (2, 32, 32, 1280, 1280, 1, 0), (2, 32, 32, 2560, 1280, 1, 0), (2, 32, 32, 1280, 1280, 1, 1),
+    (1, 1024, 1024, 128, 128, 1, 0), (1, 512, 512, 256, 256, 1, 0), (1, 256, 256, 512, 512, 1, 0), (1, 128, 128, 512, 512, 1, 0),
+    (1, 512, 512, 256, 256, 1, 1), (1, 1024, 1024, 8, 128, 1, 0), (1, 1024, 1024, 128, 4, 1, 0)]
+ATTNS = [(2, 10, 4096, 4096, 64), (2, 20, 1024, 1024, 64), (2, 10, 4096, 77, 64), (2, 20, 1024, 77, 64), (1, 1, 16384, 16384, 512),
+         (2, 12, 77, 77, 64)]
+
+
+def run(which, tiles):
+    if which in ("gemm", "all"):
+        for m, n, k in GEMMS:
+            a = torch.randn(m, k, device=DEV, dtype=torch.float16)
+            w = ctx.pack_linear(torch.randn(n, k, device=DEV, dtype=torch.float16) * k ** -0.5)
+            out = torch.empty(m, n, device=DEV, dtype=torch.float16)
+            res = []
+            for t in tiles:
+                hip.lib().fie_debug_force_tile(t)
+                dt = timeit(lambda: ctx.gemm(a, w, n, out=out))
+                res.append(f"t{t}: {dt * 1e6:8.1f} us {2 * m * n * k / dt / 1e12:7.1f} TF")
+            print(f"gemm M={m:6d} N={n:6d} K={k:6d}  " + "  ".join(res), flush=True)
+    if which in ("conv", "all"):
+        for b, h, w_, cin, cout, stride, ups in CONVS:
+            x = torch.randn(b, h, w_, cin, device=DEV, dtype=torch.float16)
+            wt = ctx.pack_conv3x3(torch.randn(cout, cin, 3, 3, device=DEV, dtype=torch.float16) * (9 * cin) ** -0.5)
+            oh, ow = (h << ups) // stride, (w_ << ups) // stride
+            res = []
+            for t in tiles:
+                hip.lib().fie_debug_force_tile(t)
+                dt = timeit(lambda: ctx.conv3x3(x, wt, (cout + 3) // 4 * 4, stride=stride, upsample=bool(ups)), iters=10)
+                res.append(f"t{t}: {dt * 1e6:8.1f} us {2 * b * oh * ow * 9 * cin * cout / dt / 1e12:7.1f} TF")
+            print(f"conv B={b} {h}x{w_} {cin}->{cout} s{stride} u{ups}  " + "  ".join(res), flush=True)
+    hip.lib().fie_debug_force_tile(0)
+    if which in ("attn", "all"):
+        for b, hn, tq, tk, d in ATTNS:
+            c = hn * d
+            q = torch.randn(b * tq, c, device=DEV, dtype=torch.float16)
+            k = torch.randn(b * tk, c, device=DEV, dtype=torch.float16)
+            v = torch.randn(b * tk, c, device=DEV, dtype=torch.float16)
+            res = []
+            for var in (1, 0):
+                hip.lib().fie_debug_attn_variant(var)
+                dt = timeit(lambda: ctx.attention(q, k, v, hn, d, tq, tk, b), iters=10)
+                res.append(f"v{2 - var}: {dt * 1e6:8.1f} us {4 * b * hn * tq * tk * d / dt / 1e12:7.1f} TF")
+            print(f"attn B={b} H={hn} Tq={tq} Tk={tk} D={d}: " + "  ".join(res), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3]
+    run(which, tiles)
