@@ -96,7 +96,7 @@ class Context:
         _chk(lib().fie_ctx_create(device, None, ctypes.byref(h)))
         self.h = h
         self._stream = None
-        self._gn_ws = None
+        self._gn_ws = {}
 
     def sync_stream(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
@@ -187,10 +187,11 @@ class Context:
         if out is None:
             out = torch.empty(x1.shape[:-1] + (c1 + c2,), device=x1.device, dtype=torch.float16)
         need = lib().fie_groupnorm_workspace_bytes(b, rows, groups)
-        if self._gn_ws is None or self._gn_ws.numel() < need:
-            self._gn_ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+        ws = self._gn_ws.get(self._stream)          # one scratch buffer per stream: concurrent streams must not share it
+        if ws is None or ws.numel() < need:
+            ws = self._gn_ws[self._stream] = torch.empty(need, device=self.device, dtype=torch.uint8)
         _chk(lib().fie_groupnorm_nhwc_f16(self.h, _p(x1), c1, _p(x2), c2, _p(out), b, rows, groups, _p(gamma),
-                                          _p(beta), float(eps), int(silu), _p(self._gn_ws)))
+                                          _p(beta), float(eps), int(silu), _p(ws)))
         return out
 
     def layernorm(self, x, gamma, beta, eps=1e-5, out=None):

@@ -300,11 +300,14 @@ class ControlNet(_CondNet):
             c = b(ctx, c, stride=2, act=hip.ACT_SILU)
         return self.ce_out(ctx, c)
 
-    def add_residuals(self, x_in, cond_emb, temb_all, text, text_len, scale, unet_skips, unet_mid):
-        """ControlNet forward whose zero-conv epilogues write `unet_skip + scale * zero_conv(.)` directly."""
+    def encode_cond(self, x_in, cond_emb, temb_all, text, text_len):
+        """ControlNet trunk: sample = conv_in(x) + cond_embedding, then the shared down/mid path."""
+        x = self.conv_in(self.ctx, x_in, residual=cond_emb)
+        return self.encode(x, temb_all, text, text_len)
+
+    def add_residuals(self, skips, mid, scale, unet_skips, unet_mid):
+        """Zero-conv epilogues write `unet_skip + scale * zero_conv(controlnet_skip)` directly (fused scale + add)."""
         ctx = self.ctx
-        x = self.conv_in(ctx, x_in, residual=cond_emb)          # sample = conv_in(x) + cond_embedding
-        skips, mid = self.encode(x, temb_all, text, text_len)
         out = []
         for z, s, u in zip(self.zero, skips, unet_skips):
             b, h, w, c = s.shape

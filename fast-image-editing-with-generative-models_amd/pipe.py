@@ -38,6 +38,7 @@ class HipImg2ImgPipeline:
         self.timing = None         # set to [] to collect per-stage HIP-event timings in run_device()
         self.use_graph = os.environ.get("FIE_NO_GRAPH", "0") != "1"
         self._graphs = {}
+        self._side = None
 
     # -- diffusers API surface the reference touches
     def set_progress_bar_config(self, **kw):          # run_batch.py:157-158
@@ -95,6 +96,11 @@ class HipImg2ImgPipeline:
             t_dev=[torch.full((nb, 1), float(st["t"]), dtype=torch.float32).to(dev) for st in steps],
             noises=[self._randn((1, 4, lh, lw), generator) for _ in range(n_noise)])
 
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.ctx.device)
+        return self._side
+
     def _mark(self, name):
         if self.timing is not None:
             ev = torch.cuda.Event(enable_timing=True)
@@ -110,12 +116,16 @@ class HipImg2ImgPipeline:
         lh, lw = h // 8, w // 8
         hw = lh * lw
         self._mark("start")
-        # 1-2. text encoders (negative prompt "" is really encoded: SURVEY 0 item 4)
-        pl, _ = self.clip_l(job["ids_l"])
-        pg, pooled = self.clip_g(job["ids_g"], eos_rows=job["eos_rows"])
-        text = torch.cat([pl, pg], dim=1)
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream()
+        # 1-2. text encoders (negative prompt "" is really encoded: SURVEY 0 item 4).  Independent of the VAE encode:
+        # issued on a second HIP stream so the latency-bound 77-token GEMMs hide under the VAE's large convs.
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            pl, _ = self.clip_l(job["ids_l"])
+            pg, pooled = self.clip_g(job["ids_g"], eos_rows=job["eos_rows"])
+            text = torch.cat([pl, pg], dim=1)
         text_len = text.shape[0] // nb
-        self._mark("clip")
         # 3. pixels
         x_img = ctx.pixels_in(job["img_u8"], True)
         cond = ctx.pixels_in(job["ctl_u8"], False, copies=nb)
@@ -127,7 +137,8 @@ class HipImg2ImgPipeline:
         sf = self.cfgs["vae"]["scaling_factor"]
         ctx.latent_prep(moments, noises.pop(0), noises.pop(0), hw, sf, steps[0]["sqrt_ab"], steps[0]["sqrt_1mab"],
                         latents, model_in)
-        self._mark("vae_encode")
+        main.wait_stream(side)
+        self._mark("clip+vae_encode")
         # 6. per-image invariants
         self.unet.begin_image(pooled, job["time_ids"])
         self.controlnet.begin_image(pooled, job["time_ids"])
@@ -139,13 +150,17 @@ class HipImg2ImgPipeline:
             tb_u = self.unet.time_rowbias(t_dev)
             tb_c = self.controlnet.time_rowbias(t_dev)
             self._mark("embed")
+            # UNet encoder and ControlNet trunk are independent until the zero-conv adds: two HIP streams, so their
+            # small-grid kernels (32x32 latent level: <= 1 block per CU each) share the 256 CUs
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                c_skips, c_mid = self.controlnet.encode_cond(model_in, cond_emb, tb_c, text, text_len)
             skips, mid = self.unet.encode(self.unet.conv_in(ctx, model_in), tb_u, text, text_len)
-            self._mark("unet")
-            skips, mid = self.controlnet.add_residuals(model_in, cond_emb, tb_c, text, text_len, job["cn_scale"],
-                                                       skips, mid)
-            self._mark("controlnet")
+            main.wait_stream(side)
+            self._mark("unet_enc+controlnet")
+            skips, mid = self.controlnet.add_residuals(c_skips, c_mid, job["cn_scale"], skips, mid)
             eps = self.unet.decode(mid, skips, tb_u, text, text_len)
-            self._mark("unet")
+            self._mark("unet_dec")
             z = None if st["last"] else noises.pop(0)
             ctx.lcm_step(eps, nb, job["guidance"], latents, z, hw, st["sqrt_ab"], st["sqrt_1mab"], st["c_skip"],
                          st["c_out"], st["sqrt_ab_prev"], st["sqrt_1mab_prev"], model_in, 1.0 / sf, decode_in)

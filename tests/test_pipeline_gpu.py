@@ -104,7 +104,8 @@ def test_unet_controlnet_eval_parity(rig, fie):
     t_dev = torch.full((2, 1), float(t), device=dev)
     tb_u, tb_c = pipe.unet.time_rowbias(t_dev), pipe.controlnet.time_rowbias(t_dev)
     skips, m = pipe.unet.encode(pipe.unet.conv_in(fie, model_in), tb_u, text_d, 77)
-    skips2, m2 = pipe.controlnet.add_residuals(model_in, cemb, tb_c, text_d, 77, 0.5, skips, m)
+    c_skips, c_mid = pipe.controlnet.encode_cond(model_in, cemb, tb_c, text_d, 77)
+    skips2, m2 = pipe.controlnet.add_residuals(c_skips, c_mid, 0.5, skips, m)
     eps = pipe.unet.decode(m2, skips2, tb_u, text_d, 77)
     assert rel_err(eps.permute(0, 3, 1, 2), ref) < 2e-2
 
