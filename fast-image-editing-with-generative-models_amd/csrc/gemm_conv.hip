@@ -31,6 +31,7 @@ struct GemmArgs {
     const half_t* res; int64_t ldr;
     float scale; int act;
     int nbm, nbn;
+    int64_t a1_bytes, a2_bytes, w_bytes;   // operand extents for the v3 buffer descriptors
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
@@ -406,6 +407,174 @@ void launch2_t(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
     hipLaunchKernelGGL((gemm2_kernel<BM, BN, ST, MODE, NW>), grid, dim3(NW * 64), lds, ctx->stream, a);
 }
 
+
+// =====================================================================================================================
+// v3 mainloop: as v2 (ST-stage LDS ring, counted vmcnt, one raw barrier per K-step) but the tiles are fetched with
+// `buffer_load_dwordx4 ... offen lds`: a wave-uniform buffer descriptor + a per-lane 32-bit byte offset that is computed
+// ONCE (GEMM) or once per 3x3 tap (conv, Cin % 64 == 0) + a scalar offset that advances per K-step.  The K loop then
+// carries no per-lane address arithmetic at all, and out-of-range lanes (im2col padding, rows >= M, K tail) use the
+// descriptor's range check (offset >= num_records reads as 0) instead of a zero page.  Needs every operand < 2 GiB.
+constexpr unsigned kOob = 0x80000000u;
+
+__device__ __forceinline__ void bload16(__amdgpu_buffer_rsrc_t rsrc, half_t* lds_dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+template <int BM, int BN, int ST, int MODE, int NW>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0
+__global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
+    constexpr int WGN = NW / 2;
+    constexpr int WM = BM / 2, WN = BN / WGN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int RA = BM / (8 * NW), RW = BN / (8 * NW);
+    constexpr int NP = RA + RW;
+    constexpr int STAGE = (BM + BN) * BK;
+    extern __shared__ __attribute__((aligned(16))) half_t smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (bid / p.nbn) * BM;
+    const int n0 = (bid % p.nbn) * BN;
+    const int lr = lane >> 3;
+    const int c8 = (lane & 7) ^ lr;
+
+    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)p.a1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, (int)p.a2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, (int)p.w_bytes, 0x00020000);
+
+    // per-lane byte offsets
+    unsigned a_off1[RA], a_off2[RA];       // GEMM: row offsets into A1 / A2;  conv: a_off1 = offset for the current tap
+    int a_ih[RA], a_iw[RA];
+    unsigned a_img[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + (wave + NW * i) * 8 + lr;
+        a_ok[i] = m < p.M;
+        if (MODE == 2) {
+            const int hw = p.OH * p.OW;
+            const int b = m / hw, rem = m - b * hw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            a_ih[i] = oh * p.stride - p.pt;
+            a_iw[i] = ow * p.stride - p.pl;
+            a_img[i] = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.Cin * 2u;
+            a_off1[i] = kOob;
+            a_off2[i] = 0;
+        } else {
+            a_off1[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda1 * 2u + c8 * 16u : kOob;
+            a_off2[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda2 * 2u + c8 * 16u : kOob;
+            a_ih[i] = a_iw[i] = 0;
+            a_img[i] = 0;
+        }
+    }
+    unsigned w_off[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) w_off[i] = (unsigned)(n0 + (wave + NW * i) * 8 + lr) * (unsigned)p.ldw * 2u + c8 * 16u;
+
+    int cs = 0, ftap = 0;
+    const int csteps = MODE == 2 ? p.Cin / BK : 1;
+    const int k1_steps = p.K1 / BK;            // GEMM: K-steps served by A1 (K1 % 64 == 0 unless K1 == K)
+    const int nk = (p.K + BK - 1) / BK;
+    const bool ktail = (p.K % BK) != 0;
+
+    auto issue = [&](int kt, int stage) {
+        half_t* sa = smem + stage * STAGE;
+        half_t* sw = sa + BM * BK;
+        if (MODE == 2) {
+            if (cs == 0) {
+                const int ky = (ftap * 11) >> 5, kx = ftap - 3 * ky;
+                const int hlim = p.H << p.ups, wlim = p.W << p.ups;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const int ih = a_ih[i] + ky, iw = a_iw[i] + kx;
+                    const bool ok = a_ok[i] && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+                    a_off1[i] = ok ? a_img[i] + (unsigned)((ih >> p.ups) * p.W + (iw >> p.ups)) * (unsigned)p.Cin * 2u + c8 * 16u : kOob;
+                }
+            }
+            const unsigned so = (unsigned)cs * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, a_off1[i], so);
+            if (++cs == csteps) { cs = 0; ++ftap; }
+        } else {
+            if (ktail && kt == nk - 1) {               // last, partial K-step: columns >= K read as zero
+                const bool in_k = kt * BK + c8 * 8 < p.K;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, in_k ? a_off1[i] : kOob, (unsigned)kt * (BK * 2));
+            } else if (kt < k1_steps || k1_steps == 0) {
+                const unsigned so = (unsigned)kt * (BK * 2);
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, a_off1[i], so);
+            } else {
+                const unsigned so = (unsigned)(kt - k1_steps) * (BK * 2);
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a2, sa + (wave + NW * i) * 512, a_off2[i], so);
+            }
+        }
+        const unsigned sow = (unsigned)kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) bload16(rs_w, sw + (wave + NW * i) * 512, w_off[i], sow);
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s)
+        if (s < nk) issue(s, s);
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int stage = 0, fill = ST - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int later = min(kt + ST - 2, nk - 1) - kt;
+        if (ST >= 4 && later == 2) wait_vm_barrier<2 * NP>();
+        else if (ST >= 3 && later >= 1) wait_vm_barrier<NP>();
+        else wait_vm_barrier<0>();
+        if (kt + ST - 1 < nk) issue(kt + ST - 1, fill);
+        const half_t* sa = smem + stage * STAGE;
+        const half_t* sw = sa + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 fw[FN], fa[FM];
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+                fw[i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * WN + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+                fa[j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + j * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+        stage = stage + 1 == ST ? 0 : stage + 1;
+        fill = fill + 1 == ST ? 0 : fill + 1;
+    }
+    epilogue<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int BM, int BN, int ST, int MODE, int NW = 4>
+void launch3_t(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
+    constexpr int lds = ST * (BM + BN) * BK * (int)sizeof(half_t);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm3_kernel<BM, BN, ST, MODE, NW>), grid, dim3(NW * 64), lds, ctx->stream, a);
+}
+
 int g_force_tile = 0;   // tuning hook (fie_debug_force_tile): 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64
 
 // tile codes: 1 = 128x128, 2 = 128x64, 3 = 64x64 (v1 register-staged kernel); 11/12/13 = v2 LDS-DMA ring, 3 stages;
@@ -413,27 +582,46 @@ int g_force_tile = 0;   // tuning hook (fie_debug_force_tile): 0 = heuristic, 1 
 template <int MODE>
 int launch(fie_ctx* ctx, GemmArgs& a) {
     auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-    // variant choice from tools/microbench.py on MI355X (profiles/r01_microbench.md): the LDS-DMA ring wins where a CU holds
-    // >= 2 blocks (128x64 x3 stages for convs, 64x64 x3 stages for small grids); large GEMM grids keep the register-staged
-    // 2-blocks-per-CU kernel
+    // variant choice from tools/microbench.py on MI355X (profiles/r01_microbench.md).  v3 (buffer-load LDS-DMA ring) wins
+    // wherever it is eligible; 128x64 x 3 stages is the workhorse, 64x64 for grids that would not fill the CUs, the
+    // 8-wave 128x128 block for large N x K.  Ineligible shapes fall back to the v2 / v1 kernels.
     const int64_t cus = ctx->num_cus;
+    const bool ok3 = a.a1_bytes < (1ll << 31) && a.a2_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) &&
+                     (MODE == 1 ? a.Cin % BK == 0 : (a.K1 == a.K || a.K1 % BK == 0));
     int code;
     if (MODE == 1) {
-        code = a.Cin % BK == 0 ? 12 : 2;
+        code = ok3 ? 42 : (a.Cin % BK == 0 ? 12 : 2);
     } else if (a.N >= 2048 && a.K >= 1024 && blocks(128, 128) >= cus) {
-        code = 1;
-    } else if (blocks(128, 64) >= cus * 7 / 2) {
-        code = 2;
+        code = ok3 ? 51 : 1;
+    } else if (blocks(128, 64) >= cus * 7 / 2 || a.K >= 4096) {
+        code = ok3 ? 42 : 2;
     } else {
-        code = 13;
+        code = ok3 ? 43 : 13;
     }
     if (g_force_tile) code = g_force_tile;
     const int tile = code % 10, ver = code / 10;
     const int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
-    FIE_REQUIRE(ver <= 3 && tile >= 1 && tile <= 3 && !(ver == 3 && tile == 3), "bad tile code %d", code);
+    FIE_REQUIRE(ver <= 5 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5) && tile == 3), "bad tile code %d", code);
     a.nbm = (a.M + bm - 1) / bm;
     a.nbn = (a.N + bn - 1) / bn;
     const dim3 grid((unsigned)(a.nbm * a.nbn)), block(256);
+    if (ver >= 4) {      // v3 (buffer-load LDS-DMA): needs < 2 GiB operands, tap-aligned / K1-aligned K-steps
+        if (!ok3) {
+            if (g_force_tile) { fie_set_error("tile code %d: shape not eligible for the v3 kernel", code); return FIE_EINVAL; }
+        } else {
+            constexpr int M3 = MODE == 1 ? 2 : 0;
+            if (ver == 4) {
+                if (tile == 1) launch3_t<128, 128, 3, M3>(ctx, a, grid);
+                else if (tile == 2) launch3_t<128, 64, 3, M3>(ctx, a, grid);
+                else launch3_t<64, 64, 3, M3>(ctx, a, grid);
+            } else {
+                if (tile == 1) launch3_t<128, 128, 3, M3, 8>(ctx, a, grid);
+                else launch3_t<128, 64, 3, M3, 8>(ctx, a, grid);
+            }
+            FIE_LAUNCH_CHECK();
+            return FIE_OK;
+        }
+    }
     constexpr int M2 = MODE;     // v2 conv: fast path when a K-step never straddles a tap
     const bool fast = MODE == 1 && a.Cin % BK == 0;
     if (ver == 0) {
@@ -535,6 +723,9 @@ int fie_gemm_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void*
     a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
     a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     a.res = (const half_t*)residual; a.ldr = ldr; a.scale = scale; a.act = act;
+    a.a1_bytes = ((int64_t)(M - 1) * lda1 + K1) * 2;
+    a.a2_bytes = A2 ? ((int64_t)(M - 1) * lda2 + (K - K1)) * 2 : 0;
+    a.w_bytes = fie_roundup(N, 128) * ldw * 2;
     return launch<0>(ctx, a);
 }
 
@@ -564,6 +755,9 @@ int fie_conv3x3_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int C
     a.M = B * OH * OW; a.N = Cout; a.K = K; a.K1 = K;
     a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
     a.rows_per_batch = OH * OW; a.res = (const half_t*)residual; a.ldr = ldr; a.scale = scale; a.act = act;
+    a.a1_bytes = (int64_t)B * H * W * Cin * 2;
+    a.a2_bytes = 0;
+    a.w_bytes = fie_roundup(Cout, 128) * ldw * 2;
     return launch<1>(ctx, a);
 }
 

@@ -221,7 +221,7 @@ def test_clip_embed(fie):
     assert rel_err(out, ref) < 2e-3
 
 
-@pytest.mark.parametrize("code", [1, 2, 3, 11, 12, 13, 22, 23, 31, 32])
+@pytest.mark.parametrize("code", [1, 2, 3, 11, 12, 13, 22, 23, 31, 32, 41, 42, 43, 51, 52])
 def test_gemm_conv_every_kernel_variant(fie, code):
     """Every tile / pipeline variant behind the tuning hook gives the same results (v1 register-staged, v2 LDS-DMA ring)."""
     from fie_amd import hip
@@ -243,8 +243,12 @@ def test_gemm_conv_every_kernel_variant(fie, code):
             if pad_mode == 1:
                 xi = F.pad(xi, (0, 1, 0, 1))
             ref = F.conv2d(xi, wt.float(), None, stride=stride, padding=1 if pad_mode == 0 else 0)
-            out = fie.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), fie.pack_conv3x3(wt.to(DEV)), cout, stride=stride,
-                              pad_mode=pad_mode, upsample=ups)
+            try:
+                out = fie.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), fie.pack_conv3x3(wt.to(DEV)), cout,
+                                  stride=stride, pad_mode=pad_mode, upsample=ups)
+            except hip.FieError as e:        # v3 refuses (loudly) shapes whose K-steps straddle a tap
+                assert code >= 40 and cin % 64 != 0 and "not eligible" in str(e)
+                continue
             assert rel_err(out.permute(0, 3, 1, 2), ref) < 3e-3
     finally:
         hip.lib().fie_debug_force_tile(0)
