@@ -32,6 +32,7 @@ struct GemmArgs {
     float scale; int act;
     int nbm, nbn;
     int64_t a1_bytes, a2_bytes, w_bytes;   // operand extents for the v3 buffer descriptors
+    int order;                              // 0: n-tiles fastest (an XCD owns a range of rows), 1: m-tiles fastest (an XCD owns a range of columns)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
@@ -106,8 +107,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int m0 = (bid / p.nbn) * BM;
-    const int n0 = (bid % p.nbn) * BN;
+    const int m0 = (p.order ? bid % p.nbm : bid / p.nbn) * BM;
+    const int n0 = (p.order ? bid / p.nbm : bid % p.nbn) * BN;
 
     const int c8 = tid & 7;          // chunk column inside the K-step
     const int r0 = tid >> 3;         // 0..31
@@ -266,8 +267,8 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs p) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int m0 = (bid / p.nbn) * BM;
-    const int n0 = (bid % p.nbn) * BN;
+    const int m0 = (p.order ? bid % p.nbm : bid / p.nbn) * BM;
+    const int n0 = (p.order ? bid / p.nbm : bid % p.nbn) * BN;
 
     const int lr = lane >> 3;                          // row inside a piece
     const int c8 = (lane & 7) ^ lr;                    // logical 16-byte chunk this lane fetches (source-side swizzle)
@@ -440,8 +441,8 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int m0 = (bid / p.nbn) * BM;
-    const int n0 = (bid % p.nbn) * BN;
+    const int m0 = (p.order ? bid % p.nbm : bid / p.nbn) * BM;
+    const int n0 = (p.order ? bid / p.nbm : bid % p.nbn) * BN;
     const int lr = lane >> 3;
     const int c8 = (lane & 7) ^ lr;
 
@@ -575,6 +576,7 @@ void launch3_t(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
     hipLaunchKernelGGL((gemm3_kernel<BM, BN, ST, MODE, NW>), grid, dim3(NW * 64), lds, ctx->stream, a);
 }
 
+int g_force_order = -1;  // tuning hook: -1 = estimate, 0 / 1 = force the tile order
 int g_force_tile = 0;   // tuning hook (fie_debug_force_tile): 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64
 
 // tile codes: 1 = 128x128, 2 = 128x64, 3 = 64x64 (v1 register-staged kernel); 11/12/13 = v2 LDS-DMA ring, 3 stages;
@@ -588,9 +590,19 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     const int64_t cus = ctx->num_cus;
     const bool ok3 = a.a1_bytes < (1ll << 31) && a.a2_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) &&
                      (MODE == 1 ? a.Cin % BK == 0 : (a.K1 == a.K || a.K1 % BK == 0));
+    // Global->LDS bandwidth per CU (~30 B/clk measured) caps a tile at BM*BN/(BM+BN) FLOP per byte: 256x128 / 256x256
+    // blocks (8 waves) where the grid still fills the chip, 128x64 otherwise, 64x64 for the smallest grids.
+    const int64_t b62 = blocks(256, 128), b61 = blocks(256, 256);
     int code;
     if (MODE == 1) {
-        code = ok3 ? 42 : (a.Cin % BK == 0 ? 12 : 2);
+        if (!ok3) code = a.Cin % BK == 0 ? 12 : 2;
+        else if (a.N % 256 == 0 && b61 >= 2 * cus) code = 61;
+        else if (a.N % 128 == 0 && b62 >= 150) code = 62;
+        else code = 42;
+    } else if (ok3 && a.N % 256 == 0 && a.K >= 2048 && b61 >= 2 * cus) {
+        code = 61;
+    } else if (ok3 && a.N % 128 == 0 && a.N >= 1536 && a.K >= 512 && b62 >= 200) {
+        code = 62;
     } else if (a.N >= 2048 && a.K >= 1024 && blocks(128, 128) >= cus) {
         code = ok3 ? 51 : 1;
     } else if (blocks(128, 64) >= cus * 7 / 2 || a.K >= 4096) {
@@ -600,17 +612,30 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     }
     if (g_force_tile) code = g_force_tile;
     const int tile = code % 10, ver = code / 10;
-    const int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
-    FIE_REQUIRE(ver <= 5 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5) && tile == 3), "bad tile code %d", code);
+    int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
+    if (ver == 6) { bm = 256; bn = tile == 1 ? 256 : 128; }     // 61 = 256x256 x2 stages, 62 = 256x128 x3 stages (8 waves)
+    FIE_REQUIRE(ver <= 6 && tile >= 1 && tile <= 3 && !((ver == 3 || ver >= 5) && tile == 3), "bad tile code %d", code);
     a.nbm = (a.M + bm - 1) / bm;
     a.nbn = (a.N + bn - 1) / bn;
+    {
+        // Which operand should stay resident in an XCD's 4 MiB L2?  Consecutive tile ids run on one XCD, so the fastest
+        // tile index decides what is re-streamed from the Infinity Cache / HBM.  Estimate both orders' traffic.
+        const double l2 = 3.0e6, abytes = (double)a.M * a.K * 2 * (MODE == 1 ? 1.0 / 9 : 1.0), wbytes = (double)a.N * a.K * 2;
+        const double row_major = abytes + (wbytes <= l2 ? 8 * wbytes : a.nbm * wbytes);
+        const double col_major = wbytes + (abytes <= l2 ? 8 * abytes : (wbytes / 8 <= l2 ? 8 * abytes : a.nbn * abytes));
+        (void)row_major; (void)col_major;   // measured (profiles/r01_microbench.md): the estimate does not pay; rows-per-XCD stays the default
+        a.order = g_force_order >= 0 ? g_force_order : 0;
+    }
     const dim3 grid((unsigned)(a.nbm * a.nbn)), block(256);
     if (ver >= 4) {      // v3 (buffer-load LDS-DMA): needs < 2 GiB operands, tap-aligned / K1-aligned K-steps
         if (!ok3) {
             if (g_force_tile) { fie_set_error("tile code %d: shape not eligible for the v3 kernel", code); return FIE_EINVAL; }
         } else {
             constexpr int M3 = MODE == 1 ? 2 : 0;
-            if (ver == 4) {
+            if (ver == 6) {
+                if (tile == 1) launch3_t<256, 256, 2, M3, 8>(ctx, a, grid);
+                else launch3_t<256, 128, 3, M3, 8>(ctx, a, grid);
+            } else if (ver == 4) {
                 if (tile == 1) launch3_t<128, 128, 3, M3>(ctx, a, grid);
                 else if (tile == 2) launch3_t<128, 64, 3, M3>(ctx, a, grid);
                 else launch3_t<64, 64, 3, M3>(ctx, a, grid);
@@ -701,7 +726,8 @@ __global__ void pack_conv_kernel(const half_t* src, int Cout, int Cin, int cin_p
 extern "C" {
 
 int fie_debug_force_tile(int t) {
-    g_force_tile = t;
+    g_force_order = t >= 1000 ? (t / 1000) - 1 : -1;      // 1000 + code: order 0, 2000 + code: order 1
+    g_force_tile = t % 1000;
     return FIE_OK;
 }
 
