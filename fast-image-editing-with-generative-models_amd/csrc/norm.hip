@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const half_t* X, int64_t ldx, h
     }
 }
 
-int gn_plan(GnArgs& p, int C, int G, int64_t rows, int* csplit) {
+int gn_plan(GnArgs& p, int C, int G, int64_t rows, int B, int* csplit) {
     const int nc8 = C / 8;
     int split = (nc8 + GN_THREADS - 1) / GN_THREADS;
     while (split <= nc8 && (nc8 % split != 0 || ((nc8 / split) * 8) % (C / G) != 0)) ++split;
@@ -203,14 +203,13 @@ int gn_plan(GnArgs& p, int C, int G, int64_t rows, int* csplit) {
     p.ncol = nc8 / split;
     p.rpp = GN_THREADS / p.ncol;
     *csplit = split;
-    int64_t rpc = rows / 512;
-    if (rpc < 16) rpc = 16;
-    rpc = fie_roundup(rpc, p.rpp);
+    // aim at ~2048 blocks per launch: small tensors (the 32x32 / 64x64 latent levels) are latency-bound otherwise --
+    // a thread should walk only a handful of rows
+    int64_t want = 2048 / (B > 0 ? B : 1);
+    if (want < 1) want = 1;
+    if (want > GN_MAX_CHUNKS) want = GN_MAX_CHUNKS;
+    int64_t rpc = fie_roundup((rows + want - 1) / want, p.rpp);
     int64_t nch = (rows + rpc - 1) / rpc;
-    if (nch > GN_MAX_CHUNKS) {
-        rpc = fie_roundup((rows + GN_MAX_CHUNKS - 1) / GN_MAX_CHUNKS, p.rpp);
-        nch = (rows + rpc - 1) / rpc;
-    }
     p.rows_per_chunk = (int)rpc;
     p.nchunks = (int)nch;
     return 0;
@@ -237,7 +236,7 @@ int fie_groupnorm_nhwc_f16(fie_ctx* ctx, const void* X1, int C1, const void* X2,
     p.C = C; p.G = groups; p.cg = C / groups; p.rows = rows_per_image;
     p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.eps = eps; p.silu = silu;
     int csplit = 1;
-    FIE_REQUIRE(gn_plan(p, C, groups, rows_per_image, &csplit) == 0,
+    FIE_REQUIRE(gn_plan(p, C, groups, rows_per_image, B, &csplit) == 0,
                 "fie_groupnorm_nhwc_f16: cannot split C=%d (groups=%d) into aligned column blocks", C, groups);
     p.partial = (float*)workspace;
     p.stats = p.partial + (int64_t)B * GN_MAX_CHUNKS * groups * 2;

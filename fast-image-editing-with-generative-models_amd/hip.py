@@ -97,6 +97,7 @@ class Context:
         self.h = h
         self._stream = None
         self._gn_ws = {}
+        self.ws_tag = 0
 
     def sync_stream(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
@@ -187,9 +188,10 @@ class Context:
         if out is None:
             out = torch.empty(x1.shape[:-1] + (c1 + c2,), device=x1.device, dtype=torch.float16)
         need = lib().fie_groupnorm_workspace_bytes(b, rows, groups)
-        ws = self._gn_ws.get(self._stream)          # one scratch buffer per stream: concurrent streams must not share it
+        key = (self._stream, self.ws_tag)            # one scratch buffer per stream (and per in-flight graph slot)
+        ws = self._gn_ws.get(key)
         if ws is None or ws.numel() < need:
-            ws = self._gn_ws[self._stream] = torch.empty(need, device=self.device, dtype=torch.uint8)
+            ws = self._gn_ws[key] = torch.empty(need, device=self.device, dtype=torch.uint8)
         _chk(lib().fie_groupnorm_nhwc_f16(self.h, _p(x1), c1, _p(x2), c2, _p(out), b, rows, groups, _p(gamma),
                                           _p(beta), float(eps), int(silu), _p(ws)))
         return out

@@ -175,11 +175,13 @@ class HipImg2ImgPipeline:
 
     _TENSOR_KEYS = ("ids_l", "ids_g", "eos_rows", "img_u8", "ctl_u8", "time_ids")
 
-    def run_device_graphed(self, job):
+    def run_device_graphed(self, job, slot=0):
         """run_device() replayed from a hipGraph: the ~2 500 launches of one edit are captured once per
         (size, CFG batch, step plan, scales) and replayed with the job's inputs copied into the graph's static buffers.
-        The returned u8 image is the graph's static output buffer (consume it before the next replay)."""
-        key = (job["hw"], job["nb"], tuple(st["t"] for st in job["steps"]), job["guidance"], job["cn_scale"])
+        The returned u8 image is the graph's static output buffer (consume it before the next replay).
+        `slot` selects an independent graph instance (own static buffers / scratch) so that several edits can be in
+        flight on different streams of one GPU."""
+        key = (job["hw"], job["nb"], tuple(st["t"] for st in job["steps"]), job["guidance"], job["cn_scale"], slot)
         entry = self._graphs.get(key)
         if entry is None:
             static = dict(job)
@@ -188,11 +190,13 @@ class HipImg2ImgPipeline:
             static["noises"] = [n.clone() for n in job["noises"]]
             static["t_dev"] = [t.clone() for t in job["t_dev"]]
             timing, self.timing = self.timing, None
+            self.ctx.ws_tag = slot
             self.run_device(static)                     # eager warm-up: lazy workspaces / function attributes
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.run_device(static)
+            self.ctx.ws_tag = 0
             self.timing = timing
             entry = self._graphs[key] = (graph, static, out)
         graph, static, out = entry
