@@ -487,7 +487,6 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
 
     auto issue = [&](int kt, int stage) {
         half_t* sa = smem + stage * STAGE;
-        half_t* sw = sa + BM * BK;
         if (MODE == 2) {
             if (cs == 0) {
                 const int ky = (ftap * 11) >> 5, kx = ftap - 3 * ky;
@@ -518,6 +517,9 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
                 for (int i = 0; i < RA; ++i) bload16(rs_a2, sa + (wave + NW * i) * 512, a_off2[i], so);
             }
         }
+    };
+    auto issue_w = [&](int kt, int stage) {
+        half_t* sw = smem + stage * STAGE + BM * BK;
         const unsigned sow = (unsigned)kt * (BK * 2);
 #pragma unroll
         for (int i = 0; i < RW; ++i) bload16(rs_w, sw + (wave + NW * i) * 512, w_off[i], sow);
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
 
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
-        if (s < nk) issue(s, s);
+        if (s < nk) { issue(s, s); issue_w(s, s); }
 
     const int fr = lane & 15, fq = lane >> 4;
     int stage = 0, fill = ST - 1;
@@ -540,11 +542,18 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         if (ST >= 4 && later == 2) wait_vm_barrier<2 * NP>();
         else if (ST >= 3 && later >= 1) wait_vm_barrier<NP>();
         else wait_vm_barrier<0>();
-        if (kt + ST - 1 < nk) issue(kt + ST - 1, fill);
+        const bool more = kt + ST - 1 < nk;
         const half_t* sa = smem + stage * STAGE;
         const half_t* sw = sa + BM * BK;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            // the refill of the freed stage is issued in two halves, one in front of each MFMA group, so that no wave
+            // spends a whole K-step's worth of LDS-DMA issue slots before its first MFMA
+            // (measured: pays for the 8-wave blocks, costs 10 % on the 4-wave ones, which keep one burst per K-step)
+            if (more) {
+                if (kk == 0) { issue(kt + ST - 1, fill); if (NW != 8) issue_w(kt + ST - 1, fill); }
+                else if (NW == 8) issue_w(kt + ST - 1, fill);
+            }
             f16x8 fw[FN], fa[FM];
 #pragma unroll
             for (int i = 0; i < FN; ++i)
@@ -552,11 +561,13 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < FM; ++j)
                 fa[j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + j * 16 + fr, kk * 4 + fq));
+            if (NW == 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
                 for (int j = 0; j < FM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+            if (NW == 8) __builtin_amdgcn_s_setprio(0);
         }
         stage = stage + 1 == ST ? 0 : stage + 1;
         fill = fill + 1 == ST ? 0 : fill + 1;
