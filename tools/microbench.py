@@ -51,6 +51,16 @@ def run(which, tiles):
                 dt = timeit(lambda: ctx.gemm(a, w, n, out=out))
                 res.append(f"t{t}: {dt * 1e6:8.1f} us {2 * m * n * k / dt / 1e12:7.1f} TF")
             print(f"gemm M={m:6d} N={n:6d} K={k:6d}  " + "  ".join(res), flush=True)
+            if n >= 5120:       # FF1 shapes: also with the production epilogue (bias + GEGLU)
+                wg = ctx.pack_linear(torch.randn(n, k, device=DEV, dtype=torch.float16) * k ** -0.5, geglu=True)
+                bias = torch.randn(n, device=DEV, dtype=torch.float16)
+                outg = torch.empty(m, n // 2, device=DEV, dtype=torch.float16)
+                res = []
+                for t in tiles:
+                    hip.lib().fie_debug_force_tile(t)
+                    dt = timeit(lambda: ctx.gemm(a, wg, n, out=outg, bias=bias, act=hip.ACT_GEGLU))
+                    res.append(f"t{t}: {dt * 1e6:8.1f} us {2 * m * n * k / dt / 1e12:7.1f} TF")
+                print(f"  +bias+GEGLU epilogue            " + "  ".join(res), flush=True)
     if which in ("conv", "all"):
         for b, h, w_, cin, cout, stride, ups in CONVS:
             x = torch.randn(b, h, w_, cin, device=DEV, dtype=torch.float16)
