@@ -124,3 +124,34 @@ def test_safe_join_and_selection():
     a = ns()
     a.image_ids = ["007", "nope", "002"]
     assert [k for k, _ in run_batch.select_entries(mapping, a, mute)] == ["007", "002"]
+
+
+def test_evaluate_schema_matches_reference_results(tmp_path):
+    """evaluate.py writes the reference's metrics.csv columns and summary.json layout (evaluate.py:193-271); the
+    reference's own results/ files define the schema -- their header / key sets are restated here."""
+    import json
+    import evaluate
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    mapping = {}
+    for i in range(5):
+        rel = f"{i % 2}_cat/{i:012d}.jpg"
+        for root, jitter in (("src", 0), ("out", 12)):
+            p = tmp_path / root / rel
+            p.parent.mkdir(parents=True, exist_ok=True)
+            a = np.random.default_rng(i).integers(0, 255, (64, 64, 3)).astype(int) + rng.integers(-jitter, jitter + 1, (64, 64, 3))
+            Image.fromarray(a.clip(0, 255).astype(np.uint8)).save(p)
+        mapping[f"{i:012d}"] = {"image_path": rel, "editing_prompt": f"a [thing] {i}", "editing_type_id": str(i % 2)}
+    mapping["missing"] = {"image_path": "9_none/x.jpg", "editing_prompt": "x", "editing_type_id": "9"}
+    (tmp_path / "map.json").write_text(json.dumps(mapping))
+    evaluate.main(["--mapping_file", str(tmp_path / "map.json"), "--source_dir", str(tmp_path / "src"),
+                   "--outputs_dir", str(tmp_path / "out"), "--results_file", str(tmp_path / "r" / "metrics.csv"),
+                   "--summary_file", str(tmp_path / "r" / "summary.json"), "--device", "cpu"])
+    header = (tmp_path / "r" / "metrics.csv").read_text().splitlines()[0]
+    assert header == "image_id,image_path,editing_type_id,editing_prompt,ssim,lpips,clip_score,psnr,mse,dino_distance"
+    s = json.loads((tmp_path / "r" / "summary.json").read_text())
+    assert s["total_images"] == 5 and set(s) == {"total_images", "overall", "by_category"}
+    assert set(s["overall"]) == {"ssim", "lpips", "clip_score", "psnr", "mse", "dino_distance"}
+    assert set(s["overall"]["ssim"]) == {"mean", "std", "median"} and 0 < s["overall"]["ssim"]["mean"] < 1
+    assert set(s["by_category"]) == {"0", "1"} and s["by_category"]["0"]["count"] == 3
+    assert set(s["by_category"]["0"]["psnr"]) == {"mean", "std"} and s["overall"]["lpips"]["mean"] is None
