@@ -21,6 +21,8 @@ def env_world():
 def init(backend=None):
     """Initialise the default process group from the launcher's env (no-op for a single process)."""
     rank, local, world = env_world()
+    if world > 1 and torch.cuda.is_available():
+        torch.cuda.set_device(local)          # every launch of this process (torch's and the HIP library's) targets its GPU
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -60,7 +60,11 @@ class FastEditor:
         if self.dtype != torch.float16:
             raise NotImplementedError("fp32 (--full_precision / --quality_mode) HIP path is not built yet; "
                                       "use the default fp16 path")
-        dev_index = torch.device(device).index or 0
+        dev_index = torch.device(device).index
+        if dev_index is None:
+            dev_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        if torch.cuda.is_available():
+            torch.cuda.set_device(dev_index)      # the C-ABI launches go to the calling thread's current HIP device
         ctx = hip.context(dev_index)
         weights_dir = weights_dir or os.environ.get("FIE_WEIGHTS_DIR")
         log(f"Loading ControlNet (Canny) - {'FULL SIZE' if use_full_controlnet else 'small variant'}...")

@@ -226,3 +226,39 @@ def test_oracle_pipeline_determinism_and_step_count():
     a = opipe.edit(sds, cfgs, img, ids, ids, size=64, seed=7, strength=0.5, guidance_scale=1.0, trace=tr)
     b = opipe.edit(sds, cfgs, img, ids, ids, size=64, seed=7, strength=0.5, guidance_scale=1.0)
     assert len(tr["eps"]) == 2 and a.shape == (64, 64, 3) and np.array_equal(a, b)
+
+
+def test_directory_stack_roundtrip(tmp_path):
+    """Disk format on the weights side of the path: a diffusers-layout directory written with
+    safetensors is read back exactly, shape mismatches fail loudly, LoRA is folded, BPE files switch the tokenizer."""
+    from safetensors.torch import save_file
+    from fie_amd import stack
+    cfgs = stack.stack_configs("tiny-nomid", True)
+    sub = dict(unet="unet", controlnet="controlnet", vae="vae", clip_l="text_encoder", clip_g="text_encoder_2")
+    sds = {}
+    for i, (k, d) in enumerate(sub.items()):
+        sds[k] = weights.synth_state_dict(cfgs[k], seed=50 + i, dtype=torch.float16)
+        os.makedirs(tmp_path / d)
+        name = "diffusion_pytorch_model.fp16.safetensors" if k in ("unet", "controlnet", "vae") else "model.fp16.safetensors"
+        save_file(sds[k], str(tmp_path / d / name))
+        (tmp_path / d / "config.json").write_text(json.dumps({"_class_name": k}))
+    lora = weights.synth_lora(cfgs["unet"], seed=9, rank=4)
+    save_file(lora, str(tmp_path / "lcm_lora.safetensors"))
+    os.makedirs(tmp_path / "tokenizer")
+    (tmp_path / "tokenizer" / "vocab.json").write_text(json.dumps({"a</w>": 5}))
+    (tmp_path / "tokenizer" / "merges.txt").write_text("#version\n")
+    c2, loaded, toks = stack.directory_stack(str(tmp_path), "tiny-nomid", True)
+    assert c2 == cfgs
+    assert torch.equal(loaded["vae"]["decoder.conv_out.weight"], sds["vae"]["decoder.conv_out.weight"])
+    q = "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q.weight"
+    assert not torch.equal(loaded["unet"][q], sds["unet"][q])          # LoRA folded (tiny-nomid is an lcm_lora stack)
+    ref = dict(sds["unet"])
+    weights.fold_lora(ref, lora)
+    assert torch.equal(loaded["unet"][q], ref[q])
+    assert isinstance(toks[0], tokenizer.BpeTokenizer) and isinstance(toks[1], tokenizer.StandInTokenizer)
+    assert toks[0](["a"])[0, :3].tolist() == [49406, 5, 49407]
+    bad = dict(sds["vae"])
+    bad["decoder.conv_out.weight"] = torch.zeros(3, 7, 3, 3, dtype=torch.float16)
+    save_file(bad, str(tmp_path / "vae" / "diffusion_pytorch_model.fp16.safetensors"))
+    with pytest.raises(ValueError, match="does not match preset"):
+        stack.directory_stack(str(tmp_path), "tiny-nomid", True)

@@ -169,3 +169,35 @@ def test_graph_replay_matches_eager(rig):
     pipe.use_graph = True
     assert np.array_equal(outs[(False, 21)], outs[(True, 21)]) and np.array_equal(outs[(False, 22)], outs[(True, 22)])
     assert not np.array_equal(outs[(True, 21)], outs[(True, 22)])
+
+
+def test_run_batch_shard_end_to_end(fie, tmp_path, capsys):
+    """run_batch's per-image loop on a synthetic PIE-Bench-shaped directory: outputs land under the same relative paths,
+    --skip_existing makes reruns idempotent, a missing source / empty prompt / traversal path is counted, not fatal."""
+    import json
+    import run_batch
+    from src.pipeline import FastEditor
+    src, out = tmp_path / "src", tmp_path / "out"
+    mapping = {}
+    for i in range(3):
+        rel = f"{i}_cat/{i:012d}.jpg"
+        (src / f"{i}_cat").mkdir(parents=True)
+        synth_image(i, 96).save(src / rel)
+        mapping[f"{i:012d}"] = {"image_path": rel, "editing_prompt": f"a [blue] thing {i}", "editing_type_id": str(i)}
+    mapping["nosrc"] = {"image_path": "9_cat/none.jpg", "editing_prompt": "x", "editing_type_id": "9"}
+    mapping["noprompt"] = {"image_path": "0_cat/000000000000.jpg", "editing_prompt": "", "editing_type_id": "0"}
+    mapping["evil"] = {"image_path": "../../etc/passwd", "editing_prompt": "x", "editing_type_id": "0"}
+    args = run_batch.build_parser().parse_args(["--source_dir", str(src), "--output_dir", str(out), "--seed", "42",
+                                                "--guidance", "1.0", "--strength", "0.5", "--skip_existing"])
+    ed = FastEditor(model_name="tiny", enable_cpu_offload=False)
+    edited = out / "e"
+    entries = [(i, k, e) for i, (k, e) in enumerate(mapping.items())]
+    r1 = run_batch.process_shard(ed, entries, args, str(edited), str(out / "c"))
+    assert (r1["processed"], r1["skipped"], r1["failed"]) == (3, 1, 2)      # "noprompt" finds image 0's output: skipped
+    assert [row["index"] for row in r1["rows"]] == [0, 1, 2] and r1["total_time"] > 0
+    for i in range(3):
+        im = Image.open(edited / f"{i}_cat/{i:012d}.jpg")
+        assert im.size == (1024, 1024)
+    r2 = run_batch.process_shard(ed, entries, args, str(edited), str(out / "c"))
+    assert (r2["processed"], r2["skipped"], r2["failed"]) == (0, 4, 2)
+    assert "Invalid path" in capsys.readouterr().out
