@@ -235,6 +235,8 @@ __device__ __forceinline__ void wait_vm_barrier() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
@@ -624,8 +626,8 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     if (g_force_tile) code = g_force_tile;
     const int tile = code % 10, ver = code / 10;
     int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
-    if (ver == 6) { bm = 256; bn = tile == 1 ? 256 : 128; }     // 61 = 256x256 x2 stages, 62 = 256x128 x3 stages (8 waves)
-    FIE_REQUIRE(ver <= 6 && tile >= 1 && tile <= 3 && !((ver == 3 || ver >= 5) && tile == 3), "bad tile code %d", code);
+    if (ver == 6) { bm = 256; bn = tile == 1 ? 256 : (tile == 2 ? 128 : 320); }   // 61 = 256x256 x2, 62 = 256x128 x3, 63 = 256x320 x2 stages (8 waves)
+    FIE_REQUIRE(ver <= 6 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5) && tile == 3), "bad tile code %d", code);
     a.nbm = (a.M + bm - 1) / bm;
     a.nbn = (a.N + bn - 1) / bn;
     {
@@ -645,7 +647,8 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
             constexpr int M3 = MODE == 1 ? 2 : 0;
             if (ver == 6) {
                 if (tile == 1) launch3_t<256, 256, 2, M3, 8>(ctx, a, grid);
-                else launch3_t<256, 128, 3, M3, 8>(ctx, a, grid);
+                else if (tile == 2) launch3_t<256, 128, 3, M3, 8>(ctx, a, grid);
+                else launch3_t<256, 320, 2, M3, 8>(ctx, a, grid);
             } else if (ver == 4) {
                 if (tile == 1) launch3_t<128, 128, 3, M3>(ctx, a, grid);
                 else if (tile == 2) launch3_t<128, 64, 3, M3>(ctx, a, grid);

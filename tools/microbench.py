@@ -27,7 +27,7 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-GEMMS = [(8192, 1920, 640), (8192, 640, 640), (8192, 5120, 640), (8192, 640, 2560),
+GEMMS = [(8192, 1920, 640), (4096, 5120, 640), (1024, 10240, 1280), (8192, 640, 640), (8192, 5120, 640), (8192, 640, 2560),
          (2048, 3840, 1280), (2048, 1280, 1280), (2048, 10240, 1280), (2048, 1280, 5120),
          (154, 2560, 2048), (32768, 320, 320), (16384, 1536, 512), (4096, 4096, 4096)]
 CONVS = [  # b, h, w, cin, cout, stride, ups
