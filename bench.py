@@ -138,6 +138,33 @@ def time_unet_forward(pipe, job, iters=3):
     return best
 
 
+def time_dominant_kernel(pipe, nb, iters=20):
+    """The single kernel with the largest share of device time (profiles/r01_v3_bench_summary.md): the v3 GEMM
+    `gemm3_kernel<256,128,3,0,8>` on the UNet's 32x32-latent FF1 projection (M = nb*1024 tokens, N = 10240, K = 1280, bias +
+    GEGLU epilogue).  Average launch duration by HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K."""
+    from fie_amd import hip
+    ctx, dev = pipe.ctx, pipe.ctx.device
+    m, n, k = nb * 1024, 10240, 1280
+    g = torch.Generator(device=dev).manual_seed(1)
+    a = torch.randn((m, k), generator=g, device=dev, dtype=torch.float16)
+    w = ctx.pack_linear(torch.randn((n, k), generator=g, device=dev, dtype=torch.float16) * k ** -0.5, geglu=True)
+    bias = torch.randn((n,), generator=g, device=dev, dtype=torch.float16)
+    out = torch.empty((m, n // 2), device=dev, dtype=torch.float16)
+    for _ in range(3):
+        ctx.gemm(a, w, n, out=out, bias=bias, act=hip.ACT_GEGLU)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ctx.gemm(a, w, n, out=out, bias=bias, act=hip.ACT_GEGLU)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    tf = 2.0 * m * n * k / (us * 1e-6) / 1e12
+    return {"kernel": "gemm3_kernel<256,128,3,0,8> (FF1 GEGLU projection, 32x32 latents)", "shape": {"M": m, "N": n, "K": k},
+            "avg_us": round(us, 2), "launches": iters, "achieved": round(tf, 1), "frac": round(tf / PEAK_F16_DENSE_TFLOPS, 4),
+            "algorithmic_gflop_per_launch": round(2.0 * m * n * k / 1e9, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +265,7 @@ def main():
         for k, v in pipe.stage_ms().items():
             stage[k] = stage.get(k, 0.0) + v / 2
     pipe.timing = None
+    dominant = time_dominant_kernel(pipe, nb)
     fl = flops.image_flops(cfgs, evals, nb)
     # roofline pass: UNet alone on one stream (the overlapped production schedule interleaves ControlNet kernels)
     unet_ms_per_fwd = time_unet_forward(pipe, jobs[args.warmup])
@@ -266,7 +294,8 @@ def main():
                                                     "HIP events bracketing unet.encode + unet.decode, issued alone on one stream",
                          "achieved": round(unet_tflops, 2), "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(unet_tflops / PEAK_F16_DENSE_TFLOPS, 4), "traffic": None,
-                         "algorithmic_tflop": round(fl["unet"] * nb / 1e12, 3), "ms": round(unet_ms_per_fwd, 3)},
+                         "algorithmic_tflop": round(fl["unet"] * nb / 1e12, 3), "ms": round(unet_ms_per_fwd, 3),
+                         "dominant_kernel": dominant},
             "stage_ms": {k: round(v, 2) for k, v in stage.items()},
             "image_tflops": round(image_tflops, 2),
             "e2e_images_per_sec": round(1.0 / e2e, 4),
