@@ -225,13 +225,31 @@ __device__ __forceinline__ float max2f(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// xor-16 / xor-32 exchanges by v_permlane16_swap / v_permlane32_swap (VALU, no LDS round trip): after swap(x, y = x)
+// every lane holds {own, partner} in {r[0], r[1]}.  Two traps met on hardware / in the ISA: (1) LLVM folds swap(x, x) with
+// one SSA value on both operands as if the outputs were equal (it emitted max(r0, r0)), so the second operand is laundered
+// through an empty asm; (2) the value must come from a compiler-visible VALU op so the hazard recogniser can pad
+// "VALU write -> v_permlane read" (it cannot see into inline asm).
+__device__ __forceinline__ void swap_pair(float x, bool half32, float& a, float& b) {
+    unsigned u = __builtin_bit_cast(unsigned, x), v = u;
+    asm volatile("" : "+v"(v));
+    const auto r = half32 ? __builtin_amdgcn_permlane32_swap(u, v, false, false) : __builtin_amdgcn_permlane16_swap(u, v, false, false);
+    unsigned ra = r[0], rb = r[1];
+    asm volatile("" : "+v"(ra), "+v"(rb));         // ... and so are the two results
+    a = __builtin_bit_cast(float, ra);
+    b = __builtin_bit_cast(float, rb);
+}
 __device__ __forceinline__ float xor16_32_max(float x) {
-    x = max2f(x, __shfl_xor(x, 16));
-    return max2f(x, __shfl_xor(x, 32));
+    float a, b;
+    swap_pair(__builtin_canonicalizef(x), false, a, b);
+    swap_pair(__builtin_fmaxf(a, b), true, a, b);
+    return __builtin_fmaxf(a, b);
 }
 __device__ __forceinline__ float xor16_32_sum(float x) {
-    x += __shfl_xor(x, 16);
-    return x + __shfl_xor(x, 32);
+    float a, b;
+    swap_pair(x + 0.0f, false, a, b);
+    swap_pair(a + b, true, a, b);
+    return a + b;
 }
 
 template <int D, int QF, int KT>
