@@ -213,7 +213,6 @@ int launch_attn(fie_ctx* ctx, const AttnArgs& a, int B) {
 //     running reference only moves when a row max grows by more than 2^6 (deferred rescale) or on the first tile
 //   * masks are applied only on boundary tiles; max via v_max3 + permlane swaps; P packed with v_cvt_pkrtz and its row
 //     sum taken from the packed fp16 values with v_dot2 (numerator and denominator see the same rounding)
-__device__ __attribute__((aligned(64))) half_t g_attn_zero[512];
 
 __device__ __forceinline__ float max3f(float a, float b, float c) {
     float r;
@@ -252,6 +251,10 @@ __device__ __forceinline__ float xor16_32_sum(float x) {
     return a + b;
 }
 
+__device__ __forceinline__ void attn_bload16(__amdgpu_buffer_rsrc_t rsrc, half_t* lds_dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
 template <int D, int QF, int KT>
 __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
     constexpr int KF = KT / 16, DK = D / 32, DF = D / 16, PS = KT / 32;
@@ -275,25 +278,36 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
     const half_t* Kb = p.K + (int64_t)b * p.Tk * p.ldk + h * D;
     const half_t* Vb = p.V + (int64_t)b * p.Tk * p.ldv + h * D;
 
-    // LDS-DMA source mapping of this lane inside a piece
+    // LDS-DMA (buffer_load ... lds): per-lane byte offsets inside a tile are computed ONCE; the tile's first key enters as
+    // the scalar offset; keys >= Tk fall outside the descriptor and read as zero.  Pieces wave + 4 i: first NPT = K, rest = V.
     const int prow = lane / CH, pphys = lane % CH;
+    const int64_t kb64 = ((int64_t)(p.Tk - 1) * p.ldk + D) * 2, vb64 = ((int64_t)(p.Tk - 1) * p.ldv + D) * 2;
+    const unsigned kbytes = kb64 > 0x7fffffff ? 0x7fffffffu : (unsigned)kb64;
+    const unsigned vbytes = vb64 > 0x7fffffff ? 0x7fffffffu : (unsigned)vb64;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)kbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)vbytes, 0x00020000);
+    unsigned pvoff[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int pc = wave + 4 * i;
+        const bool isv = pc >= NPT;
+        const int row = (isv ? pc - NPT : pc) * RP + prow;
+        pvoff[i] = (unsigned)row * (unsigned)(isv ? p.ldv : p.ldk) * 2u + (unsigned)(pphys ^ (row & 7)) * 16u;
+    }
 
     auto issue = [&](int t, int stage) {
         half_t* sk = smem + stage * 2 * TILE;
         half_t* sv = sk + TILE;
-        const int key0 = t * KT;
+        const unsigned sok = (unsigned)(t * KT) * (unsigned)p.ldk * 2u, sov = (unsigned)(t * KT) * (unsigned)p.ldv * 2u;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            const int pc = wave + 4 * i;                       // 0 .. 2*NPT-1: first NPT pieces = K, rest = V
+            const int pc = wave + 4 * i;
             const bool isv = pc >= NPT;
             const int pr = isv ? pc - NPT : pc;
-            const int row = pr * RP + prow;
-            const int key = key0 + row;
-            const int chunk = pphys ^ (row & 7);
-            const half_t* src = isv ? Vb + (int64_t)key * p.ldv + chunk * 8 : Kb + (int64_t)key * p.ldk + chunk * 8;
-            if (key >= p.Tk) src = g_attn_zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)((isv ? sv : sk) + pr * 512), 16, 0, 0);
+            // (the builtin must sit in a __device__ helper: used directly in the __global__ body, the host pass silently
+            // drops the kernel's stub and the library fails to load)
+            if (isv) attn_bload16(rs_v, sv + pr * 512, pvoff[i], sov);
+            else attn_bload16(rs_k, sk + pr * 512, pvoff[i], sok);
         }
     };
 
@@ -318,15 +332,26 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
     }
 
     f32x4 o[QF][DF];
+    f32x4 negm[QF];
     float mref[QF], lrun[QF];
 #pragma unroll
     for (int a = 0; a < QF; ++a) {
         mref[a] = 0.f;
+        negm[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
         lrun[a] = 0.f;
 #pragma unroll
         for (int d = 0; d < DF; ++d) o[a][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const f16x2 ones = {(half_t)1.f, (half_t)1.f};
+    // per-lane LDS bases (halfs).  K fragment (row f*16 + fr, chunk kk*4 + fq): the swizzle only touches the low 3 chunk
+    // bits, so base[kk & 1] + (kk >> 1) * 64 + f * 16 * D.  V^T transposed read (row ps*32 [+16] + trow, chunk d*2 + c1):
+    // base[d & 3] + (d >> 2) * 64 + row constants.
+    const int trow = fq * 4 + (fr >> 2), tsub = (lane & 1) * 4, c1 = (lane & 3) >> 1;
+    int kbase[2], vbase[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) kbase[j] = fr * D + ((((j << 2) | fq) ^ (fr & 7)) << 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vbase[j] = trow * D + ((((j << 1) | c1) ^ (trow & 7)) << 3) + tsub;
 
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
@@ -335,24 +360,21 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
         const half_t* sk = smem + (t & 1) * 2 * TILE;
         const half_t* sv = sk + TILE;
 
+        // the score chains start from the persistent -m_ref registers (C operand of the first MFMA): no per-tile init
         f32x4 s[QF][KF];
-#pragma unroll
-        for (int a = 0; a < QF; ++a)
-#pragma unroll
-            for (int f = 0; f < KF; ++f) s[a][f] = (f32x4){-mref[a], -mref[a], -mref[a], -mref[a]};
 #pragma unroll
         for (int kk = 0; kk < DK; ++kk) {
 #pragma unroll
             for (int f = 0; f < KF; ++f) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + kv_off<D>(f * 16 + fr, kk * 4 + fq));
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + kbase[kk & 1] + (kk >> 1) * 64 + f * 16 * D);
 #pragma unroll
                 for (int a = 0; a < QF; ++a)
-                    s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf_[a][kk], s[a][f], 0, 0, 0);
+                    s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf_[a][kk], kk == 0 ? negm[a] : s[a][f], 0, 0, 0);
             }
         }
 
         const bool edge = (key0 + KT > p.Tk) || (p.causal && key0 + KT > q0);     // wave-uniform
-        f16x8 pf[QF][PS];
+        u32x4 pf[QF][PS];                 // packed fp16 P^T fragments: 4 dwords = 8 halfs, no half-extract/insert traffic
 #pragma unroll
         for (int a = 0; a < QF; ++a) {
             if (edge) {
@@ -378,6 +400,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
                 const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 mref[a] += delta;
+                negm[a] = (f32x4){-mref[a], -mref[a], -mref[a], -mref[a]};
                 lrun[a] *= alpha;
 #pragma unroll
                 for (int d = 0; d < DF; ++d) o[a][d] *= alpha;
@@ -391,35 +414,27 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
             for (int f = 0; f < KF; ++f) {
                 const auto lo = __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(s[a][f][0]), __builtin_amdgcn_exp2f(s[a][f][1]));
                 const auto hi = __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(s[a][f][2]), __builtin_amdgcn_exp2f(s[a][f][3]));
-                const f16x2 l2 = __builtin_bit_cast(f16x2, lo), h2 = __builtin_bit_cast(f16x2, hi);
-                sum = __builtin_amdgcn_fdot2(l2, ones, sum, false);
-                sum = __builtin_amdgcn_fdot2(h2, ones, sum, false);
-                pf[a][f >> 1][(f & 1) * 4 + 0] = l2[0];
-                pf[a][f >> 1][(f & 1) * 4 + 1] = l2[1];
-                pf[a][f >> 1][(f & 1) * 4 + 2] = h2[0];
-                pf[a][f >> 1][(f & 1) * 4 + 3] = h2[1];
+                sum = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, lo), ones, sum, false);
+                sum = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, hi), ones, sum, false);
+                pf[a][f >> 1][(f & 1) * 2 + 0] = __builtin_bit_cast(unsigned, lo);
+                pf[a][f >> 1][(f & 1) * 2 + 1] = __builtin_bit_cast(unsigned, hi);
             }
             lrun[a] += sum;
         }
 
-        const int trow = fq * 4 + (fr >> 2);
-        const int tsub = (lane & 1) * 4;
 #pragma unroll
         for (int d = 0; d < DF; ++d) {
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps) {
-                const int ra = ps * 32 + trow, rb = ra + 16;
-                const int ch = d * 2 + ((lane & 3) >> 1);
-                const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(sv + kv_off<D>(ra, ch) + tsub));
-                const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(sv + kv_off<D>(rb, ch) + tsub));
+                const half_t* vp = sv + vbase[d & 3] + (d >> 2) * 64 + ps * 32 * D;
+                const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+                const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 16 * D));
                 union { struct { s16x4 lo, hi; } s; f16x8 v; } u;
                 u.s.lo = va;
                 u.s.hi = vb;
 #pragma unroll
                 for (int a = 0; a < QF; ++a)
-                    o[a][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pf[a][ps], o[a][d], 0, 0, 0);
+                    o[a][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, __builtin_bit_cast(f16x8, pf[a][ps]), o[a][d], 0, 0, 0);
             }
         }
     }
