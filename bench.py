@@ -248,10 +248,13 @@ def main():
         single = timed_pass()
         nfl = keep
     elapsed = timed_pass()
+    per_rank = [elapsed]
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        g = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(g, t)                      # C2: gather of per-rank timings (metrics) on every rank
+        per_rank = [float(x.item()) for x in g]
+        elapsed = max(per_rank)
 
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
     evals, nb = pipe.last_stats["unet_evals"], pipe.last_stats["cfg_batch"]
@@ -299,6 +302,7 @@ def main():
             "stage_ms": {k: round(v, 2) for k, v in stage.items()},
             "image_tflops": round(image_tflops, 2),
             "e2e_images_per_sec": round(1.0 / e2e, 4),
+            "per_rank_seconds": [round(x, 4) for x in per_rank],
             "single_stream_images_per_sec": round(args.steps * world / single, 4) if single else None,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -31,6 +31,20 @@ def synthetic_stack(model_name, use_full_controlnet=False, device="cpu", dtype=t
     return cfgs, sds
 
 
+def broadcast_stack(model_name, use_full_controlnet=False, device="cpu", dtype=torch.float16, seed=1234):
+    """Multi-GPU start-up (collective C1 of SURVEY 2.3): rank 0 materialises the fp16 weights, every other rank allocates
+    receive buffers, then ONE bucketed broadcast per ~1 GiB moves them over RCCL/xGMI (gloo in the CPU tests)."""
+    import torch.distributed as dist
+    from . import dist as fdist
+    cfgs = stack_configs(model_name, use_full_controlnet)
+    if dist.get_rank() == 0:
+        _, sds = synthetic_stack(model_name, use_full_controlnet, device=device, dtype=dtype, seed=seed)
+    else:
+        sds = {k: weights.empty_state_dict(cfgs[k], device=device, dtype=dtype) for k in KEYS}
+    fdist.broadcast_state_dicts(sds, src=0, device=device)
+    return cfgs, sds
+
+
 def _tokenizer(root, sub, pad_id):
     v, m = os.path.join(root, sub, "vocab.json"), os.path.join(root, sub, "merges.txt")
     if os.path.exists(v) and os.path.exists(m):

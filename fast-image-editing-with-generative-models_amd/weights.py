@@ -239,6 +239,11 @@ def synth_state_dict(cfg, seed=1234, device="cpu", dtype=torch.float32, out_scal
     return sd
 
 
+def empty_state_dict(cfg, device="cpu", dtype=torch.float32):
+    """Uninitialised tensors with the table's names/shapes (receive buffers for the weight broadcast)."""
+    return {name: torch.empty(shape, device=device, dtype=dtype) for name, shape, _ in param_table(cfg)}
+
+
 def fold_lora(sd, lora_sd, scale=1.0):
     """W += scale * (alpha/r) * B @ A for every PEFT-style pair found.
     Accepts keys ``<module>.lora_A.weight`` / ``<module>.lora_B.weight`` (+ optional ``<module>.alpha``)."""

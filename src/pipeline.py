@@ -3,7 +3,8 @@
 Same constructor, `MODEL_CONFIGS`, `edit()` / `preprocess_image()` / `clear_memory()` / `get_memory_usage()`
 signatures, defaults, attributes and error behaviour; `self.pipe` is an `fie_amd.pipe.HipImg2ImgPipeline`
 (hand-written HIP kernels behind a C ABI) instead of the diffusers pipeline.  There is no CPU fallback: a missing
-HIP library or GPU raises.  Additive, keyword-only knobs: `weights_dir`, `seed_weights`, `noise_dtype`.
+HIP library or GPU raises.  Additive, keyword-only knobs: `weights_dir`, `seed_weights`, `noise_dtype`, `broadcast_weights`
+(under torch.distributed with world_size > 1, rank 0's synthetic weights are broadcast over RCCL instead of regenerated).
 """
 import os
 
@@ -38,7 +39,7 @@ class FastEditor:
 
     def __init__(self, model_name="sdxl", device="cuda", dtype=torch.float16, enable_cpu_offload=True,
                  use_full_precision=False, use_full_controlnet=False, *, weights_dir=None, seed_weights=1234,
-                 noise_dtype=None):
+                 noise_dtype=None, broadcast_weights=True):
         if model_name not in self.MODEL_CONFIGS and model_name not in self._EXTRA_STACKS:
             raise ValueError(f"Unknown model: {model_name}. Choose from {list(self.MODEL_CONFIGS.keys())}")
         self.model_name = model_name
@@ -76,7 +77,17 @@ class FastEditor:
         else:
             log(f"No weights directory given: seeded synthetic weights (seed {seed_weights}) for preset "
                 f"{stack.stack_configs(model_name, use_full_controlnet)['unet']['name']}")
-            cfgs, sds = stack.synthetic_stack(model_name, use_full_controlnet, device=ctx.device, seed=seed_weights)
+            cfgs = sds = None
+            if broadcast_weights and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                    and torch.distributed.get_world_size() > 1:
+                try:      # rank 0 generates, one bucketed RCCL broadcast over xGMI feeds the other ranks
+                    cfgs, sds = stack.broadcast_stack(model_name, use_full_controlnet, device=ctx.device, seed=seed_weights)
+                    log("Weights broadcast from rank 0")
+                except Exception as e:  # a broken fabric must not take the job down: every rank can regenerate from the seed
+                    log(f"weight broadcast failed ({type(e).__name__}: {e}); regenerating locally from the seed")
+                    cfgs = sds = None
+            if sds is None:
+                cfgs, sds = stack.synthetic_stack(model_name, use_full_controlnet, device=ctx.device, seed=seed_weights)
         self.presets = {k: c["name"] for k, c in cfgs.items()}
         log("Setting LCM scheduler...")
         self.pipe = HipImg2ImgPipeline(ctx, cfgs, sds, tokenizers=toks, noise_dtype=noise_dtype or self.dtype)

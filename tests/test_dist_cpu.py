@@ -77,3 +77,32 @@ def test_gloo_world2_broadcast_and_gather():
         p.join(60)
         assert p.exitcode == 0
     assert got == (7, 1, list(range(7)))
+
+
+def _bcast_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    fdist.init(backend="gloo")
+    from fie_amd import stack
+    cfgs, sds = stack.broadcast_stack("tiny", True, device="cpu", dtype=torch.float16, seed=77)
+    _, ref = stack.synthetic_stack("tiny", True, device="cpu", dtype=torch.float16, seed=77)
+    ok = all(torch.equal(sds[k][n], ref[k][n]) for k in ref for n in ref[k])
+    out.put((rank, ok, sum(len(v) for v in sds.values())))
+    fdist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gloo_world2_weight_broadcast_of_a_full_stack():
+    """C1 end to end on the tiny stack: rank 1 starts from uninitialised buffers and ends bit-identical to rank 0's weights."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=150) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [g[:2] for g in got] == [(0, True), (1, True)] and got[0][2] == got[1][2] > 1000
