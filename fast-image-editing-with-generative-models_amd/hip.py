@@ -39,6 +39,8 @@ SIGNATURES = {
     "fie_pack_rows_f16": [_P, _P, _L, _I, _I, _P, _L, _I, _I],
     "fie_pack_conv3x3_f16": [_P, _P, _I, _I, _I, _P, _L, _I],
     "fie_canny_rgb_u8": [_P, _I, _I, _I, _I, _P],
+    "fie_canny_workspace_bytes": [_I, _I],
+    "fie_canny_rgb_device_u8": [_P, _P, _I, _I, _I, _I, _P, _P, _c.POINTER(_I)],
     "fie_debug_force_tile": [_I],
     "fie_debug_attn_variant": [_I],
 }
@@ -66,7 +68,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.argtypes = args
-            fn.restype = _L if name == "fie_groupnorm_workspace_bytes" else _I
+            fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes") else _I
         _lib.fie_last_error.restype = ctypes.c_char_p
         _lib.fie_last_error.argtypes = []
     return _lib
@@ -232,6 +234,18 @@ class Context:
         _, h, w, ld = x_nhwc.shape
         out = torch.empty((h, w, 3), device=x_nhwc.device, dtype=torch.uint8)
         _chk(lib().fie_pixels_out_f16_u8(self.h, _p(x_nhwc), ld, h, w, _p(out)))
+        return out
+
+    def canny_device(self, rgb_u8, low=100, high=200):
+        """u8 [H, W, 3] device tensor -> u8 [H, W, 3] edge map on the device (integer exact; synchronises the stream)."""
+        self.sync_stream()
+        h, w, _ = rgb_u8.shape
+        assert rgb_u8.is_contiguous() and rgb_u8.dtype == torch.uint8
+        ws = torch.empty(lib().fie_canny_workspace_bytes(h, w), device=self.device, dtype=torch.uint8)
+        out = torch.empty((h, w, 3), device=self.device, dtype=torch.uint8)
+        it = _I(0)
+        _chk(lib().fie_canny_rgb_device_u8(self.h, _p(rgb_u8), h, w, int(low), int(high), _p(ws), _p(out), ctypes.byref(it)))
+        self.canny_passes = it.value
         return out
 
     def latent_prep(self, moments, eps_post, noise, hw, sf, sqrt_ab, sqrt_1mab, latents, model_in):

@@ -62,6 +62,13 @@ class HipImg2ImgPipeline:
 
     def prepare(self, prompt, negative_prompt="", image=None, control_image=None, strength=0.8,
                 num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5, generator=None):
+        """`image` / `control_image`: PIL images, or u8 [H, W, 3] tensors already on the device (FastEditor.edit keeps the
+        resized source and its device-side Canny map in HBM instead of bouncing them through PIL)."""
+        return self._prepare(prompt, negative_prompt, image, control_image, strength, num_inference_steps, guidance_scale,
+                             controlnet_conditioning_scale, generator)
+
+    def _prepare(self, prompt, negative_prompt, image, control_image, strength, num_inference_steps, guidance_scale,
+                 controlnet_conditioning_scale, generator):
         """Host side of one call: argument checks, tokenisation, RNG draws (in upstream order: posterior sample, init
         noise, one per non-final step) and the H2D copies.  Returns the device-resident job for run_device()."""
         ctx = self.ctx
@@ -69,9 +76,10 @@ class HipImg2ImgPipeline:
             raise ValueError("`image` and `control_image` are both required")
         if strength < 0 or strength > 1:
             raise ValueError(f"The value of strength should in [0.0, 1.0] but is {strength}")
-        if image.size != control_image.size:
+        size_of = lambda im: (im.shape[1], im.shape[0]) if torch.is_tensor(im) else im.size
+        if size_of(image) != size_of(control_image):
             raise ValueError("image and control_image must have the same size")
-        w, h = image.size
+        w, h = size_of(image)
         if h % 8 or w % 8:
             raise ValueError(f"`height` and `width` have to be divisible by 8 but are {h} and {w}.")
         steps = self.scheduler.plan(num_inference_steps, strength)
@@ -82,7 +90,7 @@ class HipImg2ImgPipeline:
         dev = ctx.device
         texts = [negative_prompt or "", prompt] if do_cfg else [prompt]
         lh, lw = h // 8, w // 8
-        u8 = lambda im: torch.from_numpy(np.array(im.convert("RGB"))).to(dev)
+        u8 = lambda im: im.to(dev).contiguous() if torch.is_tensor(im) else torch.from_numpy(np.array(im.convert("RGB"))).to(dev)
         n_noise = 2 + sum(1 for st in steps if not st["last"])
         nb = 2 if do_cfg else 1
         ids_g = self.tok_g(texts)

@@ -140,6 +140,14 @@ int fie_debug_attn_variant(int variant);   /* 0 = default kernel, 1 = first-gene
  * src/pipeline.py:200,205 and the 3-channel stack at :208.  rgb, edges_rgb: host u8 [H, W, 3]. */
 int fie_canny_rgb_u8(const uint8_t* rgb, int H, int W, int low, int high, uint8_t* edges_rgb);
 
+/* ---- K11 on the device: same integer-exact result as fie_canny_rgb_u8, on a u8 HWC image already in HBM.
+ *   workspace: fie_canny_workspace_bytes(H, W) bytes.  The hysteresis fixed point reads a flag back, so this entry
+ *   SYNCHRONISES the ctx stream (it runs in the host-side preparation of an edit, never inside the captured graph).
+ *   iterations (optional, host int): hysteresis passes launched. */
+int64_t fie_canny_workspace_bytes(int H, int W);
+int fie_canny_rgb_device_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int low, int high, void* workspace,
+                            uint8_t* edges_rgb, int* iterations);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,12 +99,18 @@ class FastEditor:
                                   else "disabled (faster, needs more VRAM)"))
         log("Initialization complete!")
 
-    def preprocess_image(self, image, low_threshold=100, high_threshold=200):
-        """PIL RGB -> 3-channel PIL Canny edge map (reference :183-210; integer-exact host Canny through the C ABI)."""
+    def _canny_device(self, image, low_threshold, high_threshold):
+        """PIL -> (u8 HWC source on the device, u8 HWC edge map on the device): gray, Sobel, NMS and hysteresis run in HIP
+        kernels (csrc/canny_device.hip), integer exact."""
         arr = np.array(image)
         if arr.ndim == 2:
             arr = np.stack([arr] * 3, axis=2)
-        return Image.fromarray(hip.canny_rgb(arr[..., :3], low_threshold, high_threshold))
+        src = torch.from_numpy(np.ascontiguousarray(arr[..., :3])).to(self.pipe.ctx.device)
+        return src, self.pipe.ctx.canny_device(src, low_threshold, high_threshold)
+
+    def preprocess_image(self, image, low_threshold=100, high_threshold=200):
+        """PIL RGB -> 3-channel PIL Canny edge map (reference :183-210)."""
+        return Image.fromarray(self._canny_device(image, low_threshold, high_threshold)[1].cpu().numpy())
 
     def edit(self, image, prompt, negative_prompt="", strength=0.80, num_inference_steps=4, guidance_scale=1.5,
              controlnet_conditioning_scale=0.5, canny_low_threshold=100, canny_high_threshold=200, seed=None):
@@ -113,10 +119,11 @@ class FastEditor:
         if seed is not None:
             generator = torch.Generator(device=self.device).manual_seed(seed)
         input_image = image.resize((1024, 1024), Image.LANCZOS)
-        control_image = self.preprocess_image(input_image, low_threshold=canny_low_threshold,
-                                              high_threshold=canny_high_threshold)
-        return self.pipe(prompt=prompt, negative_prompt=negative_prompt, image=input_image,
-                         control_image=control_image, strength=strength, num_inference_steps=num_inference_steps,
+        # same data flow as the reference (:251-272) with the two images kept in HBM: preprocess_image()'s PIL round trip
+        # (D2H of the edge map + H2D again inside the pipeline) is skipped
+        source_dev, control_dev = self._canny_device(input_image, canny_low_threshold, canny_high_threshold)
+        return self.pipe(prompt=prompt, negative_prompt=negative_prompt, image=source_dev,
+                         control_image=control_dev, strength=strength, num_inference_steps=num_inference_steps,
                          guidance_scale=guidance_scale, controlnet_conditioning_scale=controlnet_conditioning_scale,
                          generator=generator).images[0]
 

@@ -252,3 +252,33 @@ def test_gemm_conv_every_kernel_variant(fie, code):
             assert rel_err(out.permute(0, 3, 1, 2), ref) < 3e-3
     finally:
         hip.lib().fie_debug_force_tile(0)
+
+
+@pytest.mark.parametrize("seed,h,w,lo,hi", [(0, 64, 64, 100, 200), (1, 97, 131, 100, 200), (2, 256, 256, 50, 150), (3, 1024, 1024, 100, 200),
+                                            (4, 1024, 1024, 20, 60), (5, 33, 70, 200, 100)])
+def test_canny_device_bit_exact(fie, seed, h, w, lo, hi):
+    """Device Canny == host C++ entry == numpy oracle, bit for bit; long weak chains need several hysteresis passes."""
+    from fie_amd import hip
+    from oracle import canny as ocanny
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([128 + 100 * np.sin(xx / rng.uniform(5, 30) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(5, 30)) for _ in range(3)], 2)
+    for _ in range(10):
+        cx, cy, r = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(1, max(2, min(h, w) / 4))
+        img[((xx - cx) ** 2 + (yy - cy) ** 2) < r * r] = rng.uniform(0, 255, 3)
+    img = (img + rng.normal(0, 5, img.shape)).clip(0, 255).astype(np.uint8)
+    got = fie.canny_device(torch.from_numpy(img).to(DEV), lo, hi).cpu().numpy()
+    assert np.array_equal(got, hip.canny_rgb(img, lo, hi))
+    assert np.array_equal(got, ocanny.canny_rgb(img, lo, hi))
+    assert fie.canny_passes >= 2
+
+
+def test_canny_device_long_chain(fie):
+    """A weak ramp edge 1000 pixels long seeded by one strong pixel: the closure must cross ~32 tiles."""
+    from oracle import canny as ocanny
+    img = np.full((64, 1024, 3), 100, np.uint8)
+    img[32:, :, :] = 130                      # L1 gradient 4*30 = 120: weak everywhere (100 < 120 <= 200)
+    img[32:, :8, :] = 200                     # strong seed at the left end
+    got = fie.canny_device(torch.from_numpy(img).to(DEV), 100, 200).cpu().numpy()
+    ref = ocanny.canny_rgb(img, 100, 200)
+    assert np.array_equal(got, ref) and ref[:, 900:].max() == 255 and fie.canny_passes > 8
