@@ -577,6 +577,183 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     epilogue<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// v4 = v3's data path with a PING-PONG schedule: the block's 8 waves form two groups of 4 (one wave per SIMD each).  A K-step
+// is split into a load phase (LDS-DMA issue for step kt+2, then ALL fragment ds_reads of step kt into registers) and an
+// MFMA phase (the 2 x FN x FM MFMAs of step kt), each closed by a raw s_barrier; group 1 runs one barrier behind group 0, so
+// on every SIMD one wave streams LDS while the other feeds the matrix pipe.  Stage reuse: the DMA for step kt+2 targets the
+// stage both groups finished reading (lgkmcnt(0) before the barrier) at least one phase earlier.
+template <int BM, int BN, int ST, int MODE, int NW>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0; NW == 8, ST == 3
+__global__ __launch_bounds__(NW * 64) void gemm4_kernel(GemmArgs p) {
+    constexpr int WGN = NW / 2;
+    constexpr int WM = BM / 2, WN = BN / WGN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int RA = BM / (8 * NW), RW = BN / (8 * NW);
+    constexpr int NP = RA + RW;
+    constexpr int STAGE = (BM + BN) * BK;
+    extern __shared__ __attribute__((aligned(16))) half_t smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (p.order ? bid % p.nbm : bid / p.nbn) * BM;
+    const int n0 = (p.order ? bid / p.nbm : bid % p.nbn) * BN;
+    const int lr = lane >> 3;
+    const int c8 = (lane & 7) ^ lr;
+
+    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)p.a1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, (int)p.a2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, (int)p.w_bytes, 0x00020000);
+
+    // per-lane byte offsets
+    unsigned a_off1[RA], a_off2[RA];       // GEMM: row offsets into A1 / A2;  conv: a_off1 = offset for the current tap
+    int a_ih[RA], a_iw[RA];
+    unsigned a_img[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + (wave + NW * i) * 8 + lr;
+        a_ok[i] = m < p.M;
+        if (MODE == 2) {
+            const int hw = p.OH * p.OW;
+            const int b = m / hw, rem = m - b * hw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            a_ih[i] = oh * p.stride - p.pt;
+            a_iw[i] = ow * p.stride - p.pl;
+            a_img[i] = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.Cin * 2u;
+            a_off1[i] = kOob;
+            a_off2[i] = 0;
+        } else {
+            a_off1[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda1 * 2u + c8 * 16u : kOob;
+            a_off2[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda2 * 2u + c8 * 16u : kOob;
+            a_ih[i] = a_iw[i] = 0;
+            a_img[i] = 0;
+        }
+    }
+    unsigned w_off[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) w_off[i] = (unsigned)(n0 + (wave + NW * i) * 8 + lr) * (unsigned)p.ldw * 2u + c8 * 16u;
+
+    int cs = 0, ftap = 0;
+    const int csteps = MODE == 2 ? p.Cin / BK : 1;
+    const int k1_steps = p.K1 / BK;            // GEMM: K-steps served by A1 (K1 % 64 == 0 unless K1 == K)
+    const int nk = (p.K + BK - 1) / BK;
+    const bool ktail = (p.K % BK) != 0;
+
+    auto issue = [&](int kt, int stage) {
+        half_t* sa = smem + stage * STAGE;
+        if (MODE == 2) {
+            if (cs == 0) {
+                const int ky = (ftap * 11) >> 5, kx = ftap - 3 * ky;
+                const int hlim = p.H << p.ups, wlim = p.W << p.ups;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const int ih = a_ih[i] + ky, iw = a_iw[i] + kx;
+                    const bool ok = a_ok[i] && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+                    a_off1[i] = ok ? a_img[i] + (unsigned)((ih >> p.ups) * p.W + (iw >> p.ups)) * (unsigned)p.Cin * 2u + c8 * 16u : kOob;
+                }
+            }
+            const unsigned so = (unsigned)cs * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, a_off1[i], so);
+            if (++cs == csteps) { cs = 0; ++ftap; }
+        } else {
+            if (ktail && kt == nk - 1) {               // last, partial K-step: columns >= K read as zero
+                const bool in_k = kt * BK + c8 * 8 < p.K;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, in_k ? a_off1[i] : kOob, (unsigned)kt * (BK * 2));
+            } else if (kt < k1_steps || k1_steps == 0) {
+                const unsigned so = (unsigned)kt * (BK * 2);
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, a_off1[i], so);
+            } else {
+                const unsigned so = (unsigned)(kt - k1_steps) * (BK * 2);
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a2, sa + (wave + NW * i) * 512, a_off2[i], so);
+            }
+        }
+    };
+    auto issue_w = [&](int kt, int stage) {
+        half_t* sw = smem + stage * STAGE + BM * BK;
+        const unsigned sow = (unsigned)kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) bload16(rs_w, sw + (wave + NW * i) * 512, w_off[i], sow);
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    static_assert(NW == 8 && ST == 3, "ping-pong schedule: 8 waves, 3 stages");
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s)
+        if (s < nk) { issue(s, s); issue_w(s, s); }
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int group = wave >> 2;                       // wave-uniform: group 1 trails group 0 by one barrier
+    if (nk > 1) wait_vm_barrier<NP>(); else wait_vm_barrier<0>();     // step 0 landed for every wave
+    if (group == 1) asm volatile("s_barrier" ::: "memory");
+    int stage = 0, fill = ST - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---- load phase.  Entry condition (guaranteed by the previous barrier): stage kt has landed for every wave.
+        const bool more = kt + ST - 1 < nk;
+        if (more) { issue(kt + ST - 1, fill); issue_w(kt + ST - 1, fill); }
+        const half_t* sa = smem + stage * STAGE;
+        const half_t* sw = sa + BM * BK;
+        f16x8 fw[2][FN], fa[2][FM];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+                fw[kk][i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * WN + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+                fa[kk][j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + j * 16 + fr, kk * 4 + fq));
+        }
+        // close the phase: fragments in registers (so the stage may be refilled), and every step but the newest landed
+        if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA phase
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        stage = stage + 1 == ST ? 0 : stage + 1;
+        fill = fill + 1 == ST ? 0 : fill + 1;
+    }
+    if (group == 0) asm volatile("s_barrier" ::: "memory");   // match group 1's extra barrier: equal barrier counts per wave
+    epilogue<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+
+template <int BM, int BN, int MODE>
+void launch4_t(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
+    constexpr int lds = 3 * (BM + BN) * BK * (int)sizeof(half_t);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<BM, BN, 3, MODE, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm4_kernel<BM, BN, 3, MODE, 8>), grid, dim3(512), lds, ctx->stream, a);
+}
+
 template <int BM, int BN, int ST, int MODE, int NW = 4>
 void launch3_t(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
     constexpr int lds = ST * (BM + BN) * BK * (int)sizeof(half_t);
@@ -626,8 +803,9 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     if (g_force_tile) code = g_force_tile;
     const int tile = code % 10, ver = code / 10;
     int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
-    if (ver == 6) { bm = 256; bn = tile == 1 ? 256 : (tile == 2 ? 128 : 320); }   // 61 = 256x256 x2, 62 = 256x128 x3, 63 = 256x320 x2 stages (8 waves)
-    FIE_REQUIRE(ver <= 6 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5) && tile == 3), "bad tile code %d", code);
+    if (ver == 6) { bm = 256; bn = tile == 1 ? 256 : (tile == 2 ? 128 : 320); }
+    if (ver == 7) { bm = tile == 1 ? 128 : 256; bn = 128; }                        // 71 = ping-pong 128x128, 72 = ping-pong 256x128   // 61 = 256x256 x2, 62 = 256x128 x3, 63 = 256x320 x2 stages (8 waves)
+    FIE_REQUIRE(ver <= 7 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5 || ver == 7) && tile == 3), "bad tile code %d", code);
     a.nbm = (a.M + bm - 1) / bm;
     a.nbn = (a.N + bn - 1) / bn;
     {
@@ -645,7 +823,10 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
             if (g_force_tile) { fie_set_error("tile code %d: shape not eligible for the v3 kernel", code); return FIE_EINVAL; }
         } else {
             constexpr int M3 = MODE == 1 ? 2 : 0;
-            if (ver == 6) {
+            if (ver == 7) {
+                if (tile == 1) launch4_t<128, 128, M3>(ctx, a, grid);
+                else launch4_t<256, 128, M3>(ctx, a, grid);
+            } else if (ver == 6) {
                 if (tile == 1) launch3_t<256, 256, 2, M3, 8>(ctx, a, grid);
                 else if (tile == 2) launch3_t<256, 128, 3, M3, 8>(ctx, a, grid);
                 else launch3_t<256, 320, 2, M3, 8>(ctx, a, grid);
