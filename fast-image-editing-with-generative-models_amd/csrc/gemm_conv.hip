@@ -37,13 +37,14 @@ struct GemmArgs {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
 
-template <int FM, int FN, int WM, int WN>
+template <int FM, int FN, int WM, int WN, bool PATCH = false>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     // ---- epilogue: lane holds C[m = .. + fr][n = .. + fq*4 + (0..3)]
+    // PATCH: the block's 256 rows are a 16x16 spatial patch whose top-left output pixel has row index m0
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
-        const int m = m0 + wm * WM + j * 16 + fr;
+        const int m = PATCH ? m0 + (wm * (WM / 16) + j) * p.OW + fr : m0 + wm * WM + j * 16 + fr;
         if (m >= p.M) continue;
         const half_t* rb = nullptr;
         if (p.rowbias) rb = p.rowbias + (int64_t)(m / p.rows_per_batch) * p.ld_rowbias;
@@ -766,6 +767,130 @@ void launch3_t(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
     hipLaunchKernelGGL((gemm3_kernel<BM, BN, ST, MODE, NW>), grid, dim3(NW * 64), lds, ctx->stream, a);
 }
 
+
+// =====================================================================================================================
+// conv_halo_kernel: 3x3 / stride 1 / pad 1 convolution with INPUT REUSE ACROSS TAPS.  The im2col kernels above fetch
+// every input pixel nine times (once per tap); here a block owns a 16x16 output patch, loads its 18x18x64-channel input
+// halo ONCE per 64-channel block into LDS (rows = halo pixels, same 128-B swizzled rows) and runs the nine taps against
+// it -- only the 16 KiB weight slice changes per K-step.  Global->LDS traffic per 9 K-steps drops from 9*(32+16) KiB to
+// 48 + 9*16 KiB, which lifts the load-path cap that bounds the im2col kernels.
+// 8 waves = 2 (patch halves of 8 rows) x 4 (32 output channels each); buffer-load LDS-DMA, offsets computed once per
+// tile; weights in a 3-stage ring (2 steps ahead), halo in a 2-stage ring (one channel block ahead).
+constexpr int HALO_ROWS = 384;                 // 18*18 = 324 halo pixels, padded to 48 pieces x 8 rows
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
+    constexpr int NW = 8, BM = 256, WM = 128, WN = BN / 4, FM = 8, FN = WN / 16;
+    constexpr int RWP = BN / (8 * NW);         // weight pieces per wave per step
+    constexpr int RAP = HALO_ROWS / (8 * NW);  // halo pieces per wave per channel block (6)
+    constexpr int WSTAGE = BN * BK, ASTAGE = HALO_ROWS * BK;
+    extern __shared__ __attribute__((aligned(16))) half_t smem[];
+    half_t* const s_a = smem;                  // 2 halo stages
+    half_t* const s_w = smem + 2 * ASTAGE;     // 3 weight stages
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int patch = bid / p.nbn, n0 = (bid % p.nbn) * BN;
+    const int ppx = p.W >> 4, ppi = ppx * (p.H >> 4);
+    const int b = patch / ppi, prem = patch - b * ppi;
+    const int y0 = (prem / ppx) << 4, x0 = (prem - (prem / ppx) * ppx) << 4;
+    const int m0 = (b * p.H + y0) * p.W + x0;          // output row index of the patch's top-left pixel
+
+    const int lr = lane >> 3, c8 = (lane & 7) ^ lr;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)p.a1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, (int)p.w_bytes, 0x00020000);
+    unsigned a_off[RAP], w_off[RWP];
+#pragma unroll
+    for (int i = 0; i < RAP; ++i) {
+        const int r = (wave + NW * i) * 8 + lr;        // halo row = hy * 18 + hx
+        const int hy = r / 18, hx = r - hy * 18;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool ok = r < 324 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        a_off[i] = ok ? ((unsigned)((b * p.H + y) * p.W + x) * (unsigned)p.Cin + c8 * 8u) * 2u : kOob;
+    }
+#pragma unroll
+    for (int i = 0; i < RWP; ++i) w_off[i] = (unsigned)(n0 + (wave + NW * i) * 8 + lr) * (unsigned)p.ldw * 2u + c8 * 16u;
+
+    const int ncb = p.Cin / BK, total = ncb * 9;
+    auto issue_a = [&](int cb) {
+        half_t* dst = s_a + (cb & 1) * ASTAGE;
+#pragma unroll
+        for (int i = 0; i < RAP; ++i) bload16(rs_x, dst + (wave + NW * i) * 512, a_off[i], (unsigned)cb * (BK * 2));
+    };
+    auto issue_w = [&](int s) {                        // step s = cb * 9 + tap; weight k-offset = tap * Cin + cb * 64
+        const int cb = s / 9, tap = s - cb * 9;
+        half_t* dst = s_w + (s % 3) * WSTAGE;
+        const unsigned so = (unsigned)(tap * p.Cin + cb * BK) * 2u;
+#pragma unroll
+        for (int i = 0; i < RWP; ++i) bload16(rs_w, dst + (wave + NW * i) * 512, w_off[i], so);
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue_a(0);
+    issue_w(0);
+    if (total > 1) issue_w(1);
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int cb = 0, tap = 0;
+    bool a_issued_prev = false;                        // halo DMA issued during the previous step (younger than W(s))
+    for (int s = 0; s < total; ++s) {
+        // W(s) (and the halo of this channel block) must have landed: allow only what was issued after W(s)
+        const bool w_next = s + 1 < total;
+        if (a_issued_prev) { if (w_next) wait_vm_barrier<RAP + RWP>(); else wait_vm_barrier<RAP>(); }
+        else { if (w_next) wait_vm_barrier<RWP>(); else wait_vm_barrier<0>(); }
+        a_issued_prev = false;
+        if (tap == 0 && cb + 1 < ncb) { issue_a(cb + 1); a_issued_prev = true; }
+        if (s + 2 < total) issue_w(s + 2);
+        const half_t* sa = s_a + (cb & 1) * ASTAGE;
+        const half_t* sw = s_w + (s % 3) * WSTAGE;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 fw[FN], fa[FM];
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+                fw[i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * WN + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const int r = (wm * 8 + j + ky) * 18 + kx + fr;      // halo row of output pixel (ty = wm*8+j, tx = fr), this tap
+                fa[j] = *reinterpret_cast<const f16x8*>(sa + lds_off(r, kk * 4 + fq));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (++tap == 9) { tap = 0; ++cb; }
+    }
+    epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int BN>
+void launch_halo(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
+    constexpr int lds = (2 * HALO_ROWS + 3 * BN) * BK * (int)sizeof(half_t);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<BN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv_halo_kernel<BN>), grid, dim3(512), lds, ctx->stream, a);
+}
+
 int g_force_order = -1;  // tuning hook: -1 = estimate, 0 / 1 = force the tile order
 int g_force_tile = 0;   // tuning hook (fie_debug_force_tile): 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64
 
@@ -804,8 +929,10 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     const int tile = code % 10, ver = code / 10;
     int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
     if (ver == 6) { bm = 256; bn = tile == 1 ? 256 : (tile == 2 ? 128 : 320); }
-    if (ver == 7) { bm = tile == 1 ? 128 : 256; bn = 128; }                        // 71 = ping-pong 128x128, 72 = ping-pong 256x128   // 61 = 256x256 x2, 62 = 256x128 x3, 63 = 256x320 x2 stages (8 waves)
-    FIE_REQUIRE(ver <= 7 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5 || ver == 7) && tile == 3), "bad tile code %d", code);
+    if (ver == 7) { bm = tile == 1 ? 128 : 256; bn = 128; }
+    if (ver == 8) { bm = 256; bn = 128; }                                           // 82 = halo-reuse conv, 16x16 patch x 128 channels                        // 71 = ping-pong 128x128, 72 = ping-pong 256x128   // 61 = 256x256 x2, 62 = 256x128 x3, 63 = 256x320 x2 stages (8 waves)
+    FIE_REQUIRE(ver <= 8 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5 || ver == 7) && tile == 3) && (ver != 8 || tile == 2),
+                "bad tile code %d", code);
     a.nbm = (a.M + bm - 1) / bm;
     a.nbn = (a.N + bn - 1) / bn;
     {
@@ -818,6 +945,14 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
         a.order = g_force_order >= 0 ? g_force_order : 0;
     }
     const dim3 grid((unsigned)(a.nbm * a.nbn)), block(256);
+    if (ver == 8) {
+        const bool okh = MODE == 1 && ok3 && a.stride == 1 && a.ups == 0 && a.pt == 1 && a.H % 16 == 0 && a.W % 16 == 0;
+        if (!okh) { fie_set_error("tile code %d: shape not eligible for the halo conv kernel", code); return FIE_EINVAL; }
+        a.nbm = a.M / 256;
+        launch_halo<128>(ctx, a, dim3((unsigned)(a.nbm * a.nbn)));
+        FIE_LAUNCH_CHECK();
+        return FIE_OK;
+    }
     if (ver >= 4) {      // v3 (buffer-load LDS-DMA): needs < 2 GiB operands, tap-aligned / K1-aligned K-steps
         if (!ok3) {
             if (g_force_tile) { fie_set_error("tile code %d: shape not eligible for the v3 kernel", code); return FIE_EINVAL; }
