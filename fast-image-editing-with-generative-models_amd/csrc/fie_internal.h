@@ -52,3 +52,26 @@ __device__ __forceinline__ float fie_erf(float x) {
 }
 __device__ __forceinline__ float fie_gelu(float x) { return 0.5f * x * (1.0f + fie_erf(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float fie_qgelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+__device__ __forceinline__ float fie_gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// 8 consecutive elements <-> float[8] for either storage type (fp16: one 16-byte access, fp32: two)
+__device__ __forceinline__ void fie_load8(const half_t* p, float (&x)[8]) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (float)v[j];
+}
+__device__ __forceinline__ void fie_load8(const float* p, float (&x)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+}
+__device__ __forceinline__ void fie_store8(half_t* p, const float (&x)[8]) {
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (half_t)x[j];
+    *reinterpret_cast<f16x8*>(p) = v;
+}
+__device__ __forceinline__ void fie_store8(float* p, const float (&x)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(x[4], x[5], x[6], x[7]);
+}

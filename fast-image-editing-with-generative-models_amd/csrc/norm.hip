@@ -14,27 +14,32 @@ namespace {
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_CHUNKS = 1024;
 
-struct GnArgs {
-    const half_t* X1; int C1;
-    const half_t* X2; int C2;
-    half_t* Y;
+template <typename T>
+struct GnArgsT {
+    const T* X1; int C1;
+    const T* X2; int C2;
+    T* Y;
     int C, G, cg;
     int64_t rows;            // per image
     int rows_per_chunk, nchunks;
     int ncol;                // 8-channel column chunks handled per block (<= 256)
     int rpp;                 // rows per pass = 256 / ncol
-    const half_t* gamma; const half_t* beta;
+    const T* gamma; const T* beta;
     float eps; int silu;
     float* partial;          // [B][nchunks][G][2]
     float* stats;            // [B][G][2] mean, rstd
 };
 
-__device__ __forceinline__ f16x8 gn_load(const GnArgs& p, int64_t row_global, int c0) {
-    if (c0 < p.C1) return *reinterpret_cast<const f16x8*>(p.X1 + row_global * p.C1 + c0);
-    return *reinterpret_cast<const f16x8*>(p.X2 + row_global * p.C2 + (c0 - p.C1));
+using GnArgs = GnArgsT<half_t>;
+
+template <typename T>
+__device__ __forceinline__ void gn_load(const GnArgsT<T>& p, int64_t row_global, int c0, float (&x)[8]) {
+    if (c0 < p.C1) fie_load8(p.X1 + row_global * p.C1 + c0, x);
+    else fie_load8(p.X2 + row_global * p.C2 + (c0 - p.C1), x);
 }
 
-__global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(GnArgs p) {
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(GnArgsT<T> p) {
     __shared__ float red[GN_THREADS * 16];
     const int tid = threadIdx.x;
     const int col = tid % p.ncol, rsub = tid / p.ncol;
@@ -48,12 +53,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(GnArgs p) {
         const int64_t r_begin = (int64_t)blockIdx.x * p.rows_per_chunk;
         const int64_t r_end = min(r_begin + p.rows_per_chunk, p.rows);
         for (int64_t r = r_begin + rsub; r < r_end; r += p.rpp) {
-            const f16x8 v = gn_load(p, (int64_t)b * p.rows + r, c0);
+            float v[8];
+            gn_load(p, (int64_t)b * p.rows + r, c0, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float x = (float)v[j];
-                s[j] += x;
-                ss[j] += x * x;
+                s[j] += v[j];
+                ss[j] += v[j] * v[j];
             }
         }
     }
@@ -84,7 +89,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(GnArgs p) {
     }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(GnArgs p, int B) {
+template <typename T>
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GnArgsT<T> p, int B) {
     // one wave per (b, g): lanes stride over the chunk partials, xor-shuffle reduce in fp64
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -111,56 +117,59 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GnArgs p, int B) {
     }
 }
 
-__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgs p) {
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgsT<T> p) {
     const int tid = threadIdx.x;
     const int col = tid % p.ncol, rsub = tid / p.ncol;
     const int b = blockIdx.y;
     const int c0 = (blockIdx.z * p.ncol + col) * 8;
     if (!(rsub < p.rpp && c0 < p.C)) return;
     float sc[8], sh[8];
-    const f16x8 gm = *reinterpret_cast<const f16x8*>(p.gamma + c0);
-    const f16x8 bt = *reinterpret_cast<const f16x8*>(p.beta + c0);
+    float gm[8], bt[8];
+    fie_load8(p.gamma + c0, gm);
+    fie_load8(p.beta + c0, bt);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int g = (c0 + j) / p.cg;
         const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
-        sc[j] = rstd * (float)gm[j];
-        sh[j] = (float)bt[j] - mean * sc[j];
+        sc[j] = rstd * gm[j];
+        sh[j] = bt[j] - mean * sc[j];
     }
     const int64_t r_begin = (int64_t)blockIdx.x * p.rows_per_chunk;
     const int64_t r_end = min(r_begin + p.rows_per_chunk, p.rows);
     for (int64_t r = r_begin + rsub; r < r_end; r += p.rpp) {
         const int64_t rg = (int64_t)b * p.rows + r;
-        const f16x8 v = gn_load(p, rg, c0);
-        f16x8 o;
+        float v[8], o[8];
+        gn_load(p, rg, c0, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float y = (float)v[j] * sc[j] + sh[j];
-            if (p.silu) y = fie_silu(y);
-            o[j] = (half_t)y;
+            float y = v[j] * sc[j] + sh[j];
+            if (p.silu) y = sizeof(T) == 4 ? y / (1.0f + expf(-y)) : fie_silu(y);
+            o[j] = y;
         }
-        *reinterpret_cast<f16x8*>(p.Y + rg * p.C + c0) = o;
+        fie_store8(p.Y + rg * p.C + c0, o);
     }
 }
 
 // ---- LayerNorm: one wave per row, row kept in registers (C <= 4096)
 constexpr int LN_MAXV = 8;   // 8 chunks x 8 values per lane
 
-__global__ __launch_bounds__(256) void ln_kernel(const half_t* X, int64_t ldx, half_t* Y, int64_t ldy, int64_t rows,
-                                                 int C, const half_t* gamma, const half_t* beta, float eps) {
+template <typename T>
+__global__ __launch_bounds__(256) void ln_kernel(const T* X, int64_t ldx, T* Y, int64_t ldy, int64_t rows,
+                                                 int C, const T* gamma, const T* beta, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nch = C >> 3;
-    f16x8 v[LN_MAXV];
+    float v[LN_MAXV][8];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
-            v[i] = *reinterpret_cast<const f16x8*>(X + row * ldx + ch * 8);
+            fie_load8(X + row * ldx + ch * 8, v[i]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
+            for (int j = 0; j < 8; ++j) sum += v[i][j];
         }
     }
 #pragma unroll
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const half_t* X, int64_t ldx, h
         if (ch < nch) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float d = (float)v[i][j] - mean;
+                const float d = v[i][j] - mean;
                 var += d * d;
             }
         }
@@ -185,17 +194,18 @@ __global__ __launch_bounds__(256) void ln_kernel(const half_t* X, int64_t ldx, h
     for (int i = 0; i < LN_MAXV; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
-            const f16x8 g = *reinterpret_cast<const f16x8*>(gamma + ch * 8);
-            const f16x8 bb = *reinterpret_cast<const f16x8*>(beta + ch * 8);
-            f16x8 o;
+            float g[8], bb[8], o[8];
+            fie_load8(gamma + ch * 8, g);
+            fie_load8(beta + ch * 8, bb);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[i][j] - mean) * rstd * (float)g[j] + (float)bb[j]);
-            *reinterpret_cast<f16x8*>(Y + row * ldy + ch * 8) = o;
+            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
+            fie_store8(Y + row * ldy + ch * 8, o);
         }
     }
 }
 
-int gn_plan(GnArgs& p, int C, int G, int64_t rows, int B, int* csplit) {
+template <typename T>
+int gn_plan(GnArgsT<T>& p, int C, int G, int64_t rows, int B, int* csplit) {
     const int nc8 = C / 8;
     int split = (nc8 + GN_THREADS - 1) / GN_THREADS;
     while (split <= nc8 && (nc8 % split != 0 || ((nc8 / split) * 8) % (C / G) != 0)) ++split;
@@ -215,6 +225,41 @@ int gn_plan(GnArgs& p, int C, int G, int64_t rows, int B, int* csplit) {
     return 0;
 }
 
+template <typename T>
+int groupnorm_t(const char* who, fie_ctx* ctx, const void* X1, int C1, const void* X2, int C2, void* Y, int B, int64_t rows_per_image,
+                int groups, const void* gamma, const void* beta, float eps, int silu, void* workspace) {
+    FIE_REQUIRE(ctx && X1 && Y && gamma && beta && workspace, "%s: NULL argument", who);
+    FIE_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0 && (C2 == 0 || X2), "%s: C1=%d C2=%d invalid", who, C1, C2);
+    const int C = C1 + C2;
+    FIE_REQUIRE(B > 0 && rows_per_image > 0 && groups > 0 && C % groups == 0, "%s: bad shape C=%d G=%d", who, C, groups);
+    GnArgsT<T> p = {};
+    p.X1 = (const T*)X1; p.C1 = C1; p.X2 = (const T*)X2; p.C2 = C2; p.Y = (T*)Y;
+    p.C = C; p.G = groups; p.cg = C / groups; p.rows = rows_per_image;
+    p.gamma = (const T*)gamma; p.beta = (const T*)beta; p.eps = eps; p.silu = silu;
+    int csplit = 1;
+    FIE_REQUIRE(gn_plan(p, C, groups, rows_per_image, B, &csplit) == 0, "%s: cannot split C=%d (groups=%d) into aligned column blocks", who, C, groups);
+    p.partial = (float*)workspace;
+    p.stats = p.partial + (int64_t)B * GN_MAX_CHUNKS * groups * 2;
+    const dim3 grid((unsigned)p.nchunks, (unsigned)B, (unsigned)csplit);
+    hipLaunchKernelGGL(gn_partial_kernel<T>, grid, dim3(GN_THREADS), 0, ctx->stream, p);
+    hipLaunchKernelGGL(gn_finalize_kernel<T>, dim3((B * groups + 3) / 4), dim3(256), 0, ctx->stream, p, B);
+    hipLaunchKernelGGL(gn_apply_kernel<T>, grid, dim3(GN_THREADS), 0, ctx->stream, p);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+template <typename T>
+int layernorm_t(const char* who, fie_ctx* ctx, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int C, const void* gamma,
+                const void* beta, float eps) {
+    FIE_REQUIRE(ctx && X && Y && gamma && beta, "%s: NULL argument", who);
+    FIE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "%s: C=%d unsupported", who, C);
+    FIE_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "%s: bad strides", who);
+    hipLaunchKernelGGL(ln_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const T*)X, ldx, (T*)Y, ldy, rows, C,
+                       (const T*)gamma, (const T*)beta, eps);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -227,36 +272,23 @@ int64_t fie_groupnorm_workspace_bytes(int B, int64_t rows_per_image, int groups)
 int fie_groupnorm_nhwc_f16(fie_ctx* ctx, const void* X1, int C1, const void* X2, int C2, void* Y, int B,
                            int64_t rows_per_image, int groups, const void* gamma, const void* beta, float eps,
                            int silu, void* workspace) {
-    FIE_REQUIRE(ctx && X1 && Y && gamma && beta && workspace, "fie_groupnorm_nhwc_f16: NULL argument");
-    FIE_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0 && (C2 == 0 || X2), "fie_groupnorm_nhwc_f16: C1=%d C2=%d invalid", C1, C2);
-    const int C = C1 + C2;
-    FIE_REQUIRE(B > 0 && rows_per_image > 0 && groups > 0 && C % groups == 0, "fie_groupnorm_nhwc_f16: bad shape C=%d G=%d", C, groups);
-    GnArgs p = {};
-    p.X1 = (const half_t*)X1; p.C1 = C1; p.X2 = (const half_t*)X2; p.C2 = C2; p.Y = (half_t*)Y;
-    p.C = C; p.G = groups; p.cg = C / groups; p.rows = rows_per_image;
-    p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.eps = eps; p.silu = silu;
-    int csplit = 1;
-    FIE_REQUIRE(gn_plan(p, C, groups, rows_per_image, B, &csplit) == 0,
-                "fie_groupnorm_nhwc_f16: cannot split C=%d (groups=%d) into aligned column blocks", C, groups);
-    p.partial = (float*)workspace;
-    p.stats = p.partial + (int64_t)B * GN_MAX_CHUNKS * groups * 2;
-    const dim3 grid((unsigned)p.nchunks, (unsigned)B, (unsigned)csplit);
-    hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(GN_THREADS), 0, ctx->stream, p);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, ctx->stream, p, B);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), 0, ctx->stream, p);
-    FIE_LAUNCH_CHECK();
-    return FIE_OK;
+    return groupnorm_t<half_t>("fie_groupnorm_nhwc_f16", ctx, X1, C1, X2, C2, Y, B, rows_per_image, groups, gamma, beta, eps, silu, workspace);
+}
+
+int fie_groupnorm_nhwc_f32(fie_ctx* ctx, const void* X1, int C1, const void* X2, int C2, void* Y, int B,
+                           int64_t rows_per_image, int groups, const void* gamma, const void* beta, float eps,
+                           int silu, void* workspace) {
+    return groupnorm_t<float>("fie_groupnorm_nhwc_f32", ctx, X1, C1, X2, C2, Y, B, rows_per_image, groups, gamma, beta, eps, silu, workspace);
 }
 
 int fie_layernorm_f16(fie_ctx* ctx, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int C,
                       const void* gamma, const void* beta, float eps) {
-    FIE_REQUIRE(ctx && X && Y && gamma && beta, "fie_layernorm_f16: NULL argument");
-    FIE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "fie_layernorm_f16: C=%d unsupported", C);
-    FIE_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "fie_layernorm_f16: bad strides");
-    hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const half_t*)X, ldx,
-                       (half_t*)Y, ldy, rows, C, (const half_t*)gamma, (const half_t*)beta, eps);
-    FIE_LAUNCH_CHECK();
-    return FIE_OK;
+    return layernorm_t<half_t>("fie_layernorm_f16", ctx, X, ldx, Y, ldy, rows, C, gamma, beta, eps);
+}
+
+int fie_layernorm_f32(fie_ctx* ctx, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int C,
+                      const void* gamma, const void* beta, float eps) {
+    return layernorm_t<float>("fie_layernorm_f32", ctx, X, ldx, Y, ldy, rows, C, gamma, beta, eps);
 }
 
 }  // extern "C"

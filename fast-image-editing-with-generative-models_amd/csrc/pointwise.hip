@@ -5,7 +5,8 @@
 
 namespace {
 
-__global__ void sinusoid_kernel(const float* vals, int B, int nvals, int dim, half_t* out, int64_t ld_out, int col0) {
+template <typename T>
+__global__ void sinusoid_kernel(const float* vals, int B, int nvals, int dim, T* out, int64_t ld_out, int col0) {
     const int half = dim / 2;
     const int total = B * nvals * half;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -16,40 +17,43 @@ __global__ void sinusoid_kernel(const float* vals, int B, int nvals, int dim, ha
     // embeddings.py::get_timestep_embedding, flip_sin_to_cos=True, downscale_freq_shift=0: [cos | sin]
     const float freq = expf(-9.210340371976184f * (float)f / (float)half);
     const float arg = vals[b * nvals + v] * freq;
-    half_t* row = out + (int64_t)b * ld_out + col0 + v * dim;
-    row[f] = (half_t)cosf(arg);
-    row[half + f] = (half_t)sinf(arg);
+    T* row = out + (int64_t)b * ld_out + col0 + v * dim;
+    row[f] = (T)cosf(arg);
+    row[half + f] = (T)sinf(arg);
 }
 
-__global__ void clip_embed_kernel(const int32_t* ids, int rows, int T, int C, const half_t* tok, const half_t* pos, half_t* out) {
+template <typename E>
+__global__ void clip_embed_kernel(const int32_t* ids, int rows, int T, int C, const E* tok, const E* pos, E* out) {
     const int nch = C >> 3;
     const int64_t total = (int64_t)rows * nch;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / nch), ch = (int)(i - (int64_t)r * nch);
         const int t = r % T;
-        const f16x8 a = *reinterpret_cast<const f16x8*>(tok + (int64_t)ids[r] * C + ch * 8);
-        const f16x8 b = *reinterpret_cast<const f16x8*>(pos + (int64_t)t * C + ch * 8);
-        f16x8 o;
+        float a[8], b[8], o[8];
+        fie_load8(tok + (int64_t)ids[r] * C + ch * 8, a);
+        fie_load8(pos + (int64_t)t * C + ch * 8, b);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] + (float)b[j]);
-        *reinterpret_cast<f16x8*>(out + (int64_t)r * C + ch * 8) = o;
+        for (int j = 0; j < 8; ++j) o[j] = a[j] + b[j];
+        fie_store8(out + (int64_t)r * C + ch * 8, o);
     }
 }
 
-__global__ void pixels_in_kernel(const uint8_t* src, int64_t npix, int normalize, half_t* dst, int copies) {
+template <typename T>
+__global__ void pixels_in_kernel(const uint8_t* src, int64_t npix, int normalize, T* dst, int copies) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
-        f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float x = (float)src[i * 3 + c] / 255.0f;      // VaeImageProcessor: /255 then 2x-1
             if (normalize) x = 2.0f * x - 1.0f;
-            o[c] = (half_t)x;
+            o[c] = x;
         }
-        for (int k = 0; k < copies; ++k) *reinterpret_cast<f16x8*>(dst + ((int64_t)k * npix + i) * 8) = o;
+        for (int k = 0; k < copies; ++k) fie_store8(dst + ((int64_t)k * npix + i) * 8, o);
     }
 }
 
-__global__ void pixels_out_kernel(const half_t* src, int64_t ld, int64_t npix, uint8_t* dst) {
+template <typename T>
+__global__ void pixels_out_kernel(const T* src, int64_t ld, int64_t npix, uint8_t* dst) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -60,57 +64,63 @@ __global__ void pixels_out_kernel(const half_t* src, int64_t ld, int64_t npix, u
     }
 }
 
-__global__ void latent_prep_kernel(const half_t* moments, const float* eps_post, const float* noise, int64_t HW, float sf,
-                                   float sqrt_ab, float sqrt_1mab, float* lat, half_t* model_in, int copies) {
+template <typename T>
+__global__ void latent_prep_kernel(const T* moments, const float* eps_post, const float* noise, int64_t HW, float sf,
+                                   float sqrt_ab, float sqrt_1mab, float* lat, T* model_in, int copies) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < HW; i += (int64_t)gridDim.x * blockDim.x) {
-        const f16x8 m = *reinterpret_cast<const f16x8*>(moments + i * 8);
-        f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        float m[8], o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        fie_load8(moments + i * 8, m);
         float4 l;
         float* lp = &l.x;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float logvar = fminf(fmaxf((float)m[4 + c], -30.f), 20.f);
-            const float z0 = ((float)m[c] + expf(0.5f * logvar) * eps_post[c * HW + i]) * sf;
+            float logvar = fminf(fmaxf(m[4 + c], -30.f), 20.f);
+            const float z0 = (m[c] + expf(0.5f * logvar) * eps_post[c * HW + i]) * sf;
             const float x = sqrt_ab * z0 + sqrt_1mab * noise[c * HW + i];
             lp[c] = x;
-            o[c] = (half_t)x;
+            o[c] = x;
         }
         *reinterpret_cast<float4*>(lat + i * 4) = l;
-        for (int k = 0; k < copies; ++k) *reinterpret_cast<f16x8*>(model_in + ((int64_t)k * HW + i) * 8) = o;
+        for (int k = 0; k < copies; ++k) fie_store8(model_in + ((int64_t)k * HW + i) * 8, o);
     }
 }
 
+template <typename T>
 struct LcmArgs {
-    const half_t* eps; int64_t ld_eps; int nb; float guidance;
+    const T* eps; int64_t ld_eps; int nb; float guidance;
     float* lat; const float* noise; int64_t HW;
     float sab_t, s1mab_t, c_skip, c_out, sab_p, s1mab_p;
-    half_t* model_in; int copies; float inv_sf; half_t* decode_in;
+    T* model_in; int copies; float inv_sf; T* decode_in;
 };
 
-__global__ void lcm_step_kernel(LcmArgs p) {
+template <typename T>
+__global__ void lcm_step_kernel(LcmArgs<T> p) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.HW; i += (int64_t)gridDim.x * blockDim.x) {
-        const f16x4 e0 = *reinterpret_cast<const f16x4*>(p.eps + i * p.ld_eps);
-        f16x4 e1 = e0;
-        if (p.nb == 2) e1 = *reinterpret_cast<const f16x4*>(p.eps + (p.HW + i) * p.ld_eps);
-        float4 l = *reinterpret_cast<const float4*>(p.lat + i * 4);
-        float* lp = &l.x;
-        f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0}, od = {0, 0, 0, 0, 0, 0, 0, 0};
+        float e0[4], e1[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float e = (float)e0[c];
-            if (p.nb == 2) e = e + p.guidance * ((float)e1[c] - e);       // eps_u + g (eps_c - eps_u)
+            e0[c] = (float)p.eps[i * p.ld_eps + c];
+            e1[c] = p.nb == 2 ? (float)p.eps[(p.HW + i) * p.ld_eps + c] : e0[c];
+        }
+        float4 l = *reinterpret_cast<const float4*>(p.lat + i * 4);
+        float* lp = &l.x;
+        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0}, od[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float e = e0[c];
+            if (p.nb == 2) e = e + p.guidance * (e1[c] - e);              // eps_u + g (eps_c - eps_u)
             const float x = lp[c];
             const float x0 = (x - p.s1mab_t * e) / p.sab_t;
             float den = p.c_out * x0 + p.c_skip * x;
             if (p.noise) den = p.sab_p * den + p.s1mab_p * p.noise[c * p.HW + i];
             lp[c] = den;
-            o[c] = (half_t)den;
-            od[c] = (half_t)(den * p.inv_sf);
+            o[c] = den;
+            od[c] = den * p.inv_sf;
         }
         *reinterpret_cast<float4*>(p.lat + i * 4) = l;
         if (p.model_in)
-            for (int k = 0; k < p.copies; ++k) *reinterpret_cast<f16x8*>(p.model_in + ((int64_t)k * p.HW + i) * 8) = o;
-        if (p.decode_in) *reinterpret_cast<f16x8*>(p.decode_in + i * 8) = od;
+            for (int k = 0; k < p.copies; ++k) fie_store8(p.model_in + ((int64_t)k * p.HW + i) * 8, o);
+        if (p.decode_in) fie_store8(p.decode_in + i * 8, od);
     }
 }
 
@@ -119,68 +129,116 @@ inline unsigned grid_for(int64_t n) {
     return (unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
 }
 
+template <typename T>
+int sinusoid_t(fie_ctx* ctx, const float* vals, int B, int nvals, int dim, void* out, int64_t ld_out, int col0) {
+    FIE_REQUIRE(ctx && vals && out, "fie_sinusoid: NULL argument");
+    FIE_REQUIRE(B > 0 && nvals > 0 && dim > 0 && dim % 2 == 0 && ld_out >= col0 + nvals * dim, "fie_sinusoid: bad shape");
+    const int total = B * nvals * (dim / 2);
+    hipLaunchKernelGGL(sinusoid_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, vals, B, nvals, dim, (T*)out, ld_out, col0);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+template <typename T>
+int clip_embed_t(fie_ctx* ctx, const int32_t* ids, int B, int Tn, int C, const void* tok, const void* pos, void* out) {
+    FIE_REQUIRE(ctx && ids && tok && pos && out, "fie_clip_embed: NULL argument");
+    FIE_REQUIRE(B > 0 && Tn > 0 && C > 0 && C % 8 == 0, "fie_clip_embed: bad shape");
+    hipLaunchKernelGGL(clip_embed_kernel<T>, dim3(grid_for((int64_t)B * Tn * C / 8)), dim3(256), 0, ctx->stream, ids, B * Tn, Tn, C,
+                       (const T*)tok, (const T*)pos, (T*)out);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+template <typename T>
+int pixels_in_t(fie_ctx* ctx, const uint8_t* src, int H, int W, int normalize, void* dst, int copies) {
+    FIE_REQUIRE(ctx && src && dst && H > 0 && W > 0 && copies > 0, "fie_pixels_in: bad argument");
+    const int64_t n = (int64_t)H * W;
+    hipLaunchKernelGGL(pixels_in_kernel<T>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, src, n, normalize, (T*)dst, copies);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+template <typename T>
+int pixels_out_t(fie_ctx* ctx, const void* src, int64_t ld_in, int H, int W, uint8_t* dst) {
+    FIE_REQUIRE(ctx && src && dst && H > 0 && W > 0 && ld_in >= 3, "fie_pixels_out: bad argument");
+    const int64_t n = (int64_t)H * W;
+    hipLaunchKernelGGL(pixels_out_kernel<T>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const T*)src, ld_in, n, dst);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+template <typename T>
+int latent_prep_t(fie_ctx* ctx, const void* moments, const float* eps_post, const float* noise, int64_t HW, float sf, float sqrt_ab,
+                  float sqrt_1mab, float* latents_out, void* model_in, int copies) {
+    FIE_REQUIRE(ctx && moments && eps_post && noise && latents_out && model_in && HW > 0 && copies > 0, "fie_latent_prep: bad argument");
+    hipLaunchKernelGGL(latent_prep_kernel<T>, dim3(grid_for(HW)), dim3(256), 0, ctx->stream, (const T*)moments, eps_post, noise, HW, sf,
+                       sqrt_ab, sqrt_1mab, latents_out, (T*)model_in, copies);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+template <typename T>
+int lcm_step_t(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, float guidance, float* latents, const float* noise, int64_t HW,
+               float sqrt_ab_t, float sqrt_1mab_t, float c_skip, float c_out, float sqrt_ab_prev, float sqrt_1mab_prev, void* model_in,
+               int copies, float inv_scaling, void* decode_in) {
+    FIE_REQUIRE(ctx && eps && latents && HW > 0, "fie_lcm_step: bad argument");
+    FIE_REQUIRE(nb == 1 || nb == 2, "fie_lcm_step: nb=%d (1 or 2)", nb);
+    FIE_REQUIRE(ld_eps % 4 == 0 && ld_eps >= 4, "fie_lcm_step: ld_eps must be a multiple of 4");
+    FIE_REQUIRE(sqrt_ab_t > 0.f, "fie_lcm_step: sqrt(alpha_bar_t) must be positive");
+    LcmArgs<T> p = {(const T*)eps, ld_eps, nb, guidance, latents, noise, HW, sqrt_ab_t, sqrt_1mab_t, c_skip, c_out,
+                    sqrt_ab_prev, sqrt_1mab_prev, (T*)model_in, copies, inv_scaling, (T*)decode_in};
+    hipLaunchKernelGGL(lcm_step_kernel<T>, dim3(grid_for(HW)), dim3(256), 0, ctx->stream, p);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 int fie_sinusoid_f16(fie_ctx* ctx, const float* vals, int B, int nvals, int dim, void* out, int64_t ld_out, int col0) {
-    FIE_REQUIRE(ctx && vals && out, "fie_sinusoid_f16: NULL argument");
-    FIE_REQUIRE(B > 0 && nvals > 0 && dim > 0 && dim % 2 == 0 && ld_out >= col0 + nvals * dim, "fie_sinusoid_f16: bad shape");
-    const int total = B * nvals * (dim / 2);
-    hipLaunchKernelGGL(sinusoid_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, vals, B, nvals, dim,
-                       (half_t*)out, ld_out, col0);
-    FIE_LAUNCH_CHECK();
-    return FIE_OK;
+    return sinusoid_t<half_t>(ctx, vals, B, nvals, dim, out, ld_out, col0);
 }
-
-int fie_clip_embed_f16(fie_ctx* ctx, const int32_t* ids, int B, int T, int C, const void* tok_table,
-                       const void* pos_table, void* out) {
-    FIE_REQUIRE(ctx && ids && tok_table && pos_table && out, "fie_clip_embed_f16: NULL argument");
-    FIE_REQUIRE(B > 0 && T > 0 && C > 0 && C % 8 == 0, "fie_clip_embed_f16: bad shape");
-    hipLaunchKernelGGL(clip_embed_kernel, dim3(grid_for((int64_t)B * T * C / 8)), dim3(256), 0, ctx->stream, ids, B * T,
-                       T, C, (const half_t*)tok_table, (const half_t*)pos_table, (half_t*)out);
-    FIE_LAUNCH_CHECK();
-    return FIE_OK;
+int fie_sinusoid_f32(fie_ctx* ctx, const float* vals, int B, int nvals, int dim, void* out, int64_t ld_out, int col0) {
+    return sinusoid_t<float>(ctx, vals, B, nvals, dim, out, ld_out, col0);
 }
-
+int fie_clip_embed_f16(fie_ctx* ctx, const int32_t* ids, int B, int T, int C, const void* tok_table, const void* pos_table, void* out) {
+    return clip_embed_t<half_t>(ctx, ids, B, T, C, tok_table, pos_table, out);
+}
+int fie_clip_embed_f32(fie_ctx* ctx, const int32_t* ids, int B, int T, int C, const void* tok_table, const void* pos_table, void* out) {
+    return clip_embed_t<float>(ctx, ids, B, T, C, tok_table, pos_table, out);
+}
 int fie_pixels_in_u8_f16(fie_ctx* ctx, const uint8_t* src, int H, int W, int normalize, void* dst, int copies) {
-    FIE_REQUIRE(ctx && src && dst && H > 0 && W > 0 && copies > 0, "fie_pixels_in_u8_f16: bad argument");
-    const int64_t n = (int64_t)H * W;
-    hipLaunchKernelGGL(pixels_in_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, src, n, normalize, (half_t*)dst, copies);
-    FIE_LAUNCH_CHECK();
-    return FIE_OK;
+    return pixels_in_t<half_t>(ctx, src, H, W, normalize, dst, copies);
 }
-
+int fie_pixels_in_u8_f32(fie_ctx* ctx, const uint8_t* src, int H, int W, int normalize, void* dst, int copies) {
+    return pixels_in_t<float>(ctx, src, H, W, normalize, dst, copies);
+}
 int fie_pixels_out_f16_u8(fie_ctx* ctx, const void* src, int64_t ld_in, int H, int W, uint8_t* dst) {
-    FIE_REQUIRE(ctx && src && dst && H > 0 && W > 0 && ld_in >= 3, "fie_pixels_out_f16_u8: bad argument");
-    const int64_t n = (int64_t)H * W;
-    hipLaunchKernelGGL(pixels_out_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const half_t*)src, ld_in, n, dst);
-    FIE_LAUNCH_CHECK();
-    return FIE_OK;
+    return pixels_out_t<half_t>(ctx, src, ld_in, H, W, dst);
 }
-
+int fie_pixels_out_f32_u8(fie_ctx* ctx, const void* src, int64_t ld_in, int H, int W, uint8_t* dst) {
+    return pixels_out_t<float>(ctx, src, ld_in, H, W, dst);
+}
 int fie_latent_prep(fie_ctx* ctx, const void* moments, const float* eps_post, const float* noise, int64_t HW,
                     float scaling_factor, float sqrt_ab, float sqrt_1mab, float* latents_out, void* model_in, int copies) {
-    FIE_REQUIRE(ctx && moments && eps_post && noise && latents_out && model_in && HW > 0 && copies > 0,
-                "fie_latent_prep: bad argument");
-    hipLaunchKernelGGL(latent_prep_kernel, dim3(grid_for(HW)), dim3(256), 0, ctx->stream, (const half_t*)moments, eps_post,
-                       noise, HW, scaling_factor, sqrt_ab, sqrt_1mab, latents_out, (half_t*)model_in, copies);
-    FIE_LAUNCH_CHECK();
-    return FIE_OK;
+    return latent_prep_t<half_t>(ctx, moments, eps_post, noise, HW, scaling_factor, sqrt_ab, sqrt_1mab, latents_out, model_in, copies);
 }
-
-int fie_lcm_step(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, float guidance, float* latents,
-                 const float* noise, int64_t HW, float sqrt_ab_t, float sqrt_1mab_t, float c_skip, float c_out,
-                 float sqrt_ab_prev, float sqrt_1mab_prev, void* model_in, int copies, float inv_scaling, void* decode_in) {
-    FIE_REQUIRE(ctx && eps && latents && HW > 0, "fie_lcm_step: bad argument");
-    FIE_REQUIRE(nb == 1 || nb == 2, "fie_lcm_step: nb=%d (1 or 2)", nb);
-    FIE_REQUIRE(ld_eps % 4 == 0 && ld_eps >= 4, "fie_lcm_step: ld_eps must be a multiple of 4");
-    FIE_REQUIRE(sqrt_ab_t > 0.f, "fie_lcm_step: sqrt(alpha_bar_t) must be positive");
-    LcmArgs p = {(const half_t*)eps, ld_eps, nb, guidance, latents, noise, HW, sqrt_ab_t, sqrt_1mab_t, c_skip, c_out,
-                 sqrt_ab_prev, sqrt_1mab_prev, (half_t*)model_in, copies, inv_scaling, (half_t*)decode_in};
-    hipLaunchKernelGGL(lcm_step_kernel, dim3(grid_for(HW)), dim3(256), 0, ctx->stream, p);
-    FIE_LAUNCH_CHECK();
-    return FIE_OK;
+int fie_latent_prep_f32(fie_ctx* ctx, const void* moments, const float* eps_post, const float* noise, int64_t HW,
+                        float scaling_factor, float sqrt_ab, float sqrt_1mab, float* latents_out, void* model_in, int copies) {
+    return latent_prep_t<float>(ctx, moments, eps_post, noise, HW, scaling_factor, sqrt_ab, sqrt_1mab, latents_out, model_in, copies);
+}
+int fie_lcm_step(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, float guidance, float* latents, const float* noise, int64_t HW,
+                 float sqrt_ab_t, float sqrt_1mab_t, float c_skip, float c_out, float sqrt_ab_prev, float sqrt_1mab_prev,
+                 void* model_in, int copies, float inv_scaling, void* decode_in) {
+    return lcm_step_t<half_t>(ctx, eps, ld_eps, nb, guidance, latents, noise, HW, sqrt_ab_t, sqrt_1mab_t, c_skip, c_out, sqrt_ab_prev,
+                              sqrt_1mab_prev, model_in, copies, inv_scaling, decode_in);
+}
+int fie_lcm_step_f32(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, float guidance, float* latents, const float* noise,
+                     int64_t HW, float sqrt_ab_t, float sqrt_1mab_t, float c_skip, float c_out, float sqrt_ab_prev,
+                     float sqrt_1mab_prev, void* model_in, int copies, float inv_scaling, void* decode_in) {
+    return lcm_step_t<float>(ctx, eps, ld_eps, nb, guidance, latents, noise, HW, sqrt_ab_t, sqrt_1mab_t, c_skip, c_out, sqrt_ab_prev,
+                             sqrt_1mab_prev, model_in, copies, inv_scaling, decode_in);
 }
 
 }  // extern "C"

@@ -39,6 +39,17 @@ SIGNATURES = {
     "fie_pack_rows_f16": [_P, _P, _L, _I, _I, _P, _L, _I, _I],
     "fie_pack_conv3x3_f16": [_P, _P, _I, _I, _I, _P, _L, _I],
     "fie_canny_rgb_u8": [_P, _I, _I, _I, _I, _P],
+    "fie_gemm_f32": [_P, _P, _L, _I, _P, _L, _P, _L, _I, _P, _L, _I, _I, _I, _P, _P, _L, _I, _P, _L, _F, _I, _I, _I, _L, _L, _L, _L, _L, _L],
+    "fie_conv3x3_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P, _P, _L, _P, _L, _F, _I],
+    "fie_softmax_rows_f32": [_P, _P, _L, _I, _L, _F, _I, _I],
+    "fie_groupnorm_nhwc_f32": [_P, _P, _I, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P],
+    "fie_layernorm_f32": [_P, _P, _L, _P, _L, _L, _I, _P, _P, _F],
+    "fie_sinusoid_f32": [_P, _P, _I, _I, _I, _P, _L, _I],
+    "fie_clip_embed_f32": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "fie_pixels_in_u8_f32": [_P, _P, _I, _I, _I, _P, _I],
+    "fie_pixels_out_f32_u8": [_P, _P, _L, _I, _I, _P],
+    "fie_latent_prep_f32": [_P, _P, _P, _P, _L, _F, _F, _F, _P, _P, _I],
+    "fie_lcm_step_f32": [_P, _P, _L, _I, _F, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _I, _F, _P],
     "fie_canny_workspace_bytes": [_I, _I],
     "fie_canny_rgb_device_u8": [_P, _P, _I, _I, _I, _I, _P, _P, _c.POINTER(_I)],
     "fie_debug_force_tile": [_I],
@@ -90,7 +101,11 @@ def _p(t):
 class Context:
     """One fie_ctx per (process, device); launches go to torch's current stream on that device."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, dtype=torch.float16):
+        if dtype not in (torch.float16, torch.float32):
+            raise ValueError(f"dtype {dtype} not supported (float16 or float32)")
+        self.dtype = dtype                           # storage / arithmetic type of every op issued through this context
+        self.f32 = dtype == torch.float32
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: the fie_amd hot path has no CPU fallback")
         self.device = torch.device("cuda", device)
@@ -114,8 +129,15 @@ class Context:
 
     # ------------------------------------------------------------------ weight packing
     def pack_linear(self, w, geglu=False):
-        """[N, K] f16 -> packed [Npad][Kpad] (zero padded); geglu interleaves (value, gate) rows."""
+        """[N, K] f16 -> packed [Npad][Kpad] (zero padded); geglu interleaves (value, gate) rows.
+        fp32 contexts keep plain [N, K] fp32 weights (rows interleaved for GEGLU)."""
         self.sync_stream()
+        if self.f32:
+            w = w.to(self.device, torch.float32)
+            if geglu:
+                n = w.shape[0]
+                w = torch.stack([w[: n // 2], w[n // 2:]], 1).reshape(n, -1)
+            return w.contiguous()
         w = w.to(self.device, torch.float16).contiguous()
         n, k = w.shape
         npad, kpad = (n + 127) // 128 * 128, (k + 63) // 64 * 64
@@ -124,8 +146,14 @@ class Context:
         return out
 
     def pack_conv3x3(self, w, cin_pad=None):
-        """OIHW f16 -> packed [Npad][Kpad], k = (ky*3+kx)*cin_pad + ci."""
+        """OIHW f16 -> packed [Npad][Kpad], k = (ky*3+kx)*cin_pad + ci.  fp32 contexts: [Cout][9*cin_pad] fp32."""
         self.sync_stream()
+        if self.f32:
+            co, ci = w.shape[:2]
+            cp = cin_pad or (ci + 7) // 8 * 8
+            out = torch.zeros((co, 3, 3, cp), device=self.device, dtype=torch.float32)
+            out[..., :ci] = w.to(self.device, torch.float32).permute(0, 2, 3, 1)
+            return out.reshape(co, 9 * cp)
         w = w.to(self.device, torch.float16).contiguous()
         co, ci = w.shape[:2]
         cin_pad = cin_pad or (ci + 7) // 8 * 8
@@ -145,8 +173,14 @@ class Context:
             assert k == ktot
         nout = n // 2 if act == ACT_GEGLU else n
         if out is None:
-            out = torch.empty((m, nout), device=a.device, dtype=torch.float16)
+            out = torch.empty((m, nout), device=a.device, dtype=self.dtype)
         assert a.stride(1) == 1 and out.stride(1) == 1
+        if self.f32:
+            _chk(lib().fie_gemm_f32(self.h, _p(a), a.stride(0), k1, _p(a2), a2.stride(0) if a2 is not None else 0, _p(wp),
+                                    wp.stride(0), 0, _p(out), out.stride(0), m, n, ktot, _p(bias), _p(rowbias),
+                                    rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
+                                    residual.stride(0) if residual is not None else 0, float(scale), act, 1, 1, 0, 0, 0, 0, 0, 0))
+            return out
         _chk(lib().fie_gemm_f16(self.h, _p(a), a.stride(0), k1, _p(a2), a2.stride(0) if a2 is not None else 0,
                                 _p(wp), wp.stride(0), _p(out), out.stride(0), m, n, ktot, _p(bias), _p(rowbias),
                                 rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
@@ -164,8 +198,9 @@ class Context:
         oh, ow = (hin + pads - 3) // stride + 1, (win + pads - 3) // stride + 1
         ldc = ldc or cout
         if out is None:
-            out = (torch.zeros if ldc != cout else torch.empty)((b, oh, ow, ldc), device=x.device, dtype=torch.float16)
-        _chk(lib().fie_conv3x3_nhwc_f16(self.h, _p(x), b, h, w, cin, int(upsample), stride, pad_mode, _p(wp),
+            out = (torch.zeros if ldc != cout else torch.empty)((b, oh, ow, ldc), device=x.device, dtype=self.dtype)
+        fn = lib().fie_conv3x3_nhwc_f32 if self.f32 else lib().fie_conv3x3_nhwc_f16
+        _chk(fn(self.h, _p(x), b, h, w, cin, int(upsample), stride, pad_mode, _p(wp),
                                         wp.stride(0), _p(out), out.stride(2), cout, _p(bias), _p(rowbias),
                                         rowbias.stride(0) if rowbias is not None else 0, _p(residual),
                                         residual.stride(2) if residual is not None else 0, float(scale), act))
@@ -175,8 +210,20 @@ class Context:
         """q: [B*Tq, >=H*D] view (row stride free); k, v: [B*Tk, ...]; returns [B*Tq, H*D]."""
         self.sync_stream()
         if out is None:
-            out = torch.empty((batch * tq, heads * head_dim), device=q.device, dtype=torch.float16)
+            out = torch.empty((batch * tq, heads * head_dim), device=q.device, dtype=self.dtype)
         scale = scale if scale is not None else head_dim ** -0.5
+        if self.f32:
+            # S = Q K^T (batched over image x head) -> row softmax -> O = P V; the fp32 scores are simply materialised
+            s_ = torch.empty((batch * heads, tq, tk), device=q.device, dtype=torch.float32)
+            d = head_dim
+            _chk(lib().fie_gemm_f32(self.h, _p(q), q.stride(0), d, None, 0, _p(k), k.stride(0), 0, _p(s_), tk, tq, tk, d, None, None, 0,
+                                    0, None, 0, 1.0, ACT_NONE, batch, heads, tq * q.stride(0), d, tk * k.stride(0), d,
+                                    heads * tq * tk, tq * tk))
+            _chk(lib().fie_softmax_rows_f32(self.h, _p(s_), batch * heads * tq, tk, tk, float(scale), int(causal), tq))
+            _chk(lib().fie_gemm_f32(self.h, _p(s_), tk, tk, None, 0, _p(v), v.stride(0), 1, _p(out), out.stride(0), tq, d, tk, None,
+                                    None, 0, 0, None, 0, 1.0, ACT_NONE, batch, heads, heads * tq * tk, tq * tk, tk * v.stride(0), d,
+                                    tq * out.stride(0), d))
+            return out
         _chk(lib().fie_attention_f16(self.h, _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
                                      out.stride(0), batch, heads, tq, tk, head_dim, float(scale), int(causal)))
         return out
@@ -188,13 +235,13 @@ class Context:
         c2 = x2.shape[-1] if x2 is not None else 0
         assert x1.is_contiguous() and (x2 is None or x2.is_contiguous())
         if out is None:
-            out = torch.empty(x1.shape[:-1] + (c1 + c2,), device=x1.device, dtype=torch.float16)
+            out = torch.empty(x1.shape[:-1] + (c1 + c2,), device=x1.device, dtype=self.dtype)
         need = lib().fie_groupnorm_workspace_bytes(b, rows, groups)
         key = (self._stream, self.ws_tag)            # one scratch buffer per stream (and per in-flight graph slot)
         ws = self._gn_ws.get(key)
         if ws is None or ws.numel() < need:
             ws = self._gn_ws[key] = torch.empty(need, device=self.device, dtype=torch.uint8)
-        _chk(lib().fie_groupnorm_nhwc_f16(self.h, _p(x1), c1, _p(x2), c2, _p(out), b, rows, groups, _p(gamma),
+        _chk((lib().fie_groupnorm_nhwc_f32 if self.f32 else lib().fie_groupnorm_nhwc_f16)(self.h, _p(x1), c1, _p(x2), c2, _p(out), b, rows, groups, _p(gamma),
                                           _p(beta), float(eps), int(silu), _p(ws)))
         return out
 
@@ -202,8 +249,8 @@ class Context:
         self.sync_stream()
         rows, c = x.shape
         if out is None:
-            out = torch.empty((rows, c), device=x.device, dtype=torch.float16)
-        _chk(lib().fie_layernorm_f16(self.h, _p(x), x.stride(0), _p(out), out.stride(0), rows, c, _p(gamma), _p(beta),
+            out = torch.empty((rows, c), device=x.device, dtype=self.dtype)
+        _chk((lib().fie_layernorm_f32 if self.f32 else lib().fie_layernorm_f16)(self.h, _p(x), x.stride(0), _p(out), out.stride(0), rows, c, _p(gamma), _p(beta),
                                      float(eps)))
         return out
 
@@ -211,29 +258,29 @@ class Context:
         """vals: f32 [B, nvals] on device; writes [cos|sin] blocks of width dim into out[:, col0:]."""
         self.sync_stream()
         b, nv = vals.shape
-        _chk(lib().fie_sinusoid_f16(self.h, _p(vals), b, nv, dim, _p(out), out.stride(0), col0))
+        _chk((lib().fie_sinusoid_f32 if self.f32 else lib().fie_sinusoid_f16)(self.h, _p(vals), b, nv, dim, _p(out), out.stride(0), col0))
         return out
 
     def clip_embed(self, ids, tok, pos):
         self.sync_stream()
         b, t = ids.shape
         c = tok.shape[1]
-        out = torch.empty((b * t, c), device=tok.device, dtype=torch.float16)
-        _chk(lib().fie_clip_embed_f16(self.h, _p(ids), b, t, c, _p(tok), _p(pos), _p(out)))
+        out = torch.empty((b * t, c), device=tok.device, dtype=self.dtype)
+        _chk((lib().fie_clip_embed_f32 if self.f32 else lib().fie_clip_embed_f16)(self.h, _p(ids), b, t, c, _p(tok), _p(pos), _p(out)))
         return out
 
     def pixels_in(self, u8_hwc, normalize, copies=1):
         self.sync_stream()
         h, w, _ = u8_hwc.shape
-        out = torch.empty((copies, h, w, 8), device=u8_hwc.device, dtype=torch.float16)
-        _chk(lib().fie_pixels_in_u8_f16(self.h, _p(u8_hwc), h, w, int(normalize), _p(out), copies))
+        out = torch.empty((copies, h, w, 8), device=u8_hwc.device, dtype=self.dtype)
+        _chk((lib().fie_pixels_in_u8_f32 if self.f32 else lib().fie_pixels_in_u8_f16)(self.h, _p(u8_hwc), h, w, int(normalize), _p(out), copies))
         return out
 
     def pixels_out(self, x_nhwc):
         self.sync_stream()
         _, h, w, ld = x_nhwc.shape
         out = torch.empty((h, w, 3), device=x_nhwc.device, dtype=torch.uint8)
-        _chk(lib().fie_pixels_out_f16_u8(self.h, _p(x_nhwc), ld, h, w, _p(out)))
+        _chk((lib().fie_pixels_out_f32_u8 if self.f32 else lib().fie_pixels_out_f16_u8)(self.h, _p(x_nhwc), ld, h, w, _p(out)))
         return out
 
     def canny_device(self, rgb_u8, low=100, high=200):
@@ -250,13 +297,13 @@ class Context:
 
     def latent_prep(self, moments, eps_post, noise, hw, sf, sqrt_ab, sqrt_1mab, latents, model_in):
         self.sync_stream()
-        _chk(lib().fie_latent_prep(self.h, _p(moments), _p(eps_post), _p(noise), hw, float(sf), float(sqrt_ab),
+        _chk((lib().fie_latent_prep_f32 if self.f32 else lib().fie_latent_prep)(self.h, _p(moments), _p(eps_post), _p(noise), hw, float(sf), float(sqrt_ab),
                                    float(sqrt_1mab), _p(latents), _p(model_in), model_in.shape[0]))
 
     def lcm_step(self, eps, nb, guidance, latents, noise, hw, sab_t, s1mab_t, c_skip, c_out, sab_p, s1mab_p, model_in,
                  inv_sf, decode_in):
         self.sync_stream()
-        _chk(lib().fie_lcm_step(self.h, _p(eps), eps.shape[-1], nb, float(guidance), _p(latents), _p(noise), hw,
+        _chk((lib().fie_lcm_step_f32 if self.f32 else lib().fie_lcm_step)(self.h, _p(eps), eps.shape[-1], nb, float(guidance), _p(latents), _p(noise), hw,
                                 float(sab_t), float(s1mab_t), float(c_skip), float(c_out), float(sab_p),
                                 float(s1mab_p), _p(model_in), model_in.shape[0] if model_in is not None else 0,
                                 float(inv_sf), _p(decode_in)))
@@ -274,7 +321,8 @@ def canny_rgb(rgb_u8, low=100, high=200):
 _ctx = {}
 
 
-def context(device=0):
-    if device not in _ctx:
-        _ctx[device] = Context(device)
-    return _ctx[device]
+def context(device=0, dtype=torch.float16):
+    key = (device, dtype)
+    if key not in _ctx:
+        _ctx[key] = Context(device, dtype)
+    return _ctx[key]

@@ -19,7 +19,7 @@ F16 = torch.float16
 
 
 def _dev(ctx, t):
-    return t.to(ctx.device, F16).contiguous()
+    return t.to(ctx.device, ctx.dtype).contiguous()
 
 
 class Linear:
@@ -51,8 +51,8 @@ class Conv3:
         self.wp = ctx.pack_conv3x3(w, self.cin_pad)
         b = sd.get(name + ".bias")
         if b is not None:
-            bb = torch.zeros(self.n, dtype=F16, device=ctx.device)
-            bb[: self.cout] = b.to(ctx.device, F16)
+            bb = torch.zeros(self.n, dtype=ctx.dtype, device=ctx.device)
+            bb[: self.cout] = b.to(ctx.device, ctx.dtype)
             b = bb
         self.b = b
 
@@ -200,7 +200,7 @@ class _CondNet:
         ctx, cfg = self.ctx, self.cfg
         b = pooled.shape[0]
         ad = cfg["addition_time_embed_dim"]
-        add_in = torch.empty((b, cfg["projection_class_embeddings_input_dim"]), device=ctx.device, dtype=F16)
+        add_in = torch.empty((b, cfg["projection_class_embeddings_input_dim"]), device=ctx.device, dtype=ctx.dtype)
         add_in[:, : pooled.shape[1]] = pooled
         ctx.sinusoid(time_ids, ad, add_in, col0=pooled.shape[1])
         self.add_emb = self.a2(ctx, self.a1(ctx, add_in, act=hip.ACT_SILU))
@@ -211,7 +211,7 @@ class _CondNet:
         """silu(time_emb + add_emb) -> all resnets' time projections in one GEMM.  t_dev: f32 [B, 1] on device."""
         ctx = self.ctx
         ch0 = self.cfg["block_out_channels"][0]
-        s = torch.empty((t_dev.shape[0], ch0), device=ctx.device, dtype=F16)
+        s = torch.empty((t_dev.shape[0], ch0), device=ctx.device, dtype=ctx.dtype)
         ctx.sinusoid(t_dev, ch0, s)
         # emb = time_emb + add_emb; resnets consume Linear(SiLU(emb)): add_emb rides in as a per-row bias so the
         # second MLP GEMM's epilogue emits SiLU(emb) directly

@@ -21,7 +21,7 @@ F16 = torch.float16
 
 
 class HipImg2ImgPipeline:
-    def __init__(self, ctx, cfgs, sds, tokenizers=None, sched_cfg=None, noise_dtype=torch.float16):
+    def __init__(self, ctx, cfgs, sds, tokenizers=None, sched_cfg=None, noise_dtype=None):
         """cfgs / sds: dicts with keys unet, controlnet, vae, clip_l, clip_g (configs / diffusers-named state dicts)."""
         self.ctx, self.cfgs = ctx, cfgs
         self.unet = UNet(ctx, cfgs["unet"], sds["unet"])
@@ -32,7 +32,7 @@ class HipImg2ImgPipeline:
         self.tok_l, self.tok_g = tokenizers or (StandInTokenizer(cfgs["clip_l"]["pad_token_id"]),
                                                 StandInTokenizer(cfgs["clip_g"]["pad_token_id"]))
         self.scheduler = LCMSchedule(**(sched_cfg or LCM_SCHED))
-        self.noise_dtype = noise_dtype
+        self.noise_dtype = noise_dtype or ctx.dtype        # upstream randn_tensor draws in the pipeline dtype
         self.progress = {}
         self.last_stats = {}
         self.timing = None         # set to [] to collect per-stage HIP-event timings in run_device()
@@ -141,7 +141,7 @@ class HipImg2ImgPipeline:
         moments, _ = self.vae.encode_moments(x_img)
         noises = list(job["noises"])
         latents = torch.empty((hw, 4), device=dev, dtype=torch.float32)
-        model_in = torch.empty((nb, lh, lw, 8), device=dev, dtype=F16)
+        model_in = torch.empty((nb, lh, lw, 8), device=dev, dtype=ctx.dtype)
         sf = self.cfgs["vae"]["scaling_factor"]
         ctx.latent_prep(moments, noises.pop(0), noises.pop(0), hw, sf, steps[0]["sqrt_ab"], steps[0]["sqrt_1mab"],
                         latents, model_in)
@@ -151,7 +151,7 @@ class HipImg2ImgPipeline:
         self.unet.begin_image(pooled, job["time_ids"])
         self.controlnet.begin_image(pooled, job["time_ids"])
         cond_emb = self.controlnet.cond_embedding(cond)
-        decode_in = torch.empty((1, lh, lw, 8), device=dev, dtype=F16)
+        decode_in = torch.empty((1, lh, lw, 8), device=dev, dtype=ctx.dtype)
         self._mark("cond_embed")
         # 7. denoising loop
         for st, t_dev in zip(steps, job["t_dev"]):

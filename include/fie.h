@@ -131,6 +131,40 @@ int fie_pack_rows_f16(fie_ctx* ctx, const void* src, int64_t ld_src, int N, int 
 int fie_pack_conv3x3_f16(fie_ctx* ctx, const void* src_oihw, int Cout, int Cin, int cin_pad, void* dst,
                          int64_t ldw, int Npad);
 
+/* ---- fp32 path (`FastEditor(use_full_precision=True)`, run_batch.py --full_precision / --quality_mode; reference:
+ * src/pipeline.py:67-71,94-99).  Same graphs, fp32 storage, exact fp32 arithmetic on v_mfma_f32_16x16x4_f32.
+ *   fie_gemm_f32: as fie_gemm_f16 with plain (unpacked) weights W [N][ldw] -- or [K][ldw] when w_is_kn -- and a two-level
+ *     batch (z1 < nb1, z2 < nb2; element strides sA*, sW*, sC*) that serves the attention products over (image, head).
+ *   fie_conv3x3_nhwc_f32: weights [Cout][(ky, kx, ci)] (ldw >= 9*Cin).
+ *   fie_softmax_rows_f32: in-place softmax(scale * S) per row, keys > (row % tq) masked when causal.
+ *   the *_f32 norm / element-wise entries mirror their f16 twins with fp32 tensors. */
+int fie_gemm_f32(fie_ctx* ctx, const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, const float* W,
+                 int64_t ldw, int w_is_kn, float* C, int64_t ldc, int M, int N, int K, const float* bias,
+                 const float* rowbias, int64_t ld_rowbias, int rows_per_batch, const float* residual, int64_t ldr,
+                 float scale, int act, int nb1, int nb2, int64_t sA1, int64_t sA2, int64_t sW1, int64_t sW2, int64_t sC1,
+                 int64_t sC2);
+int fie_conv3x3_nhwc_f32(fie_ctx* ctx, const float* X, int B, int H, int W, int Cin, int upsample2x, int stride, int pad_mode,
+                         const float* Wkc, int64_t ldw, float* Y, int64_t ldc, int Cout, const float* bias,
+                         const float* rowbias, int64_t ld_rowbias, const float* residual, int64_t ldr, float scale, int act);
+int fie_softmax_rows_f32(fie_ctx* ctx, float* S, int64_t rows, int cols, int64_t ld, float scale, int causal, int tq);
+int fie_groupnorm_nhwc_f32(fie_ctx* ctx, const void* X1, int C1, const void* X2, int C2, void* Y, int B,
+                           int64_t rows_per_image, int groups, const void* gamma, const void* beta, float eps,
+                           int silu, void* workspace);
+int fie_layernorm_f32(fie_ctx* ctx, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int C,
+                      const void* gamma, const void* beta, float eps);
+int fie_sinusoid_f32(fie_ctx* ctx, const float* vals, int B, int nvals, int dim, void* out, int64_t ld_out, int col0);
+int fie_clip_embed_f32(fie_ctx* ctx, const int32_t* ids, int B, int T, int C, const void* tok_table,
+                       const void* pos_table, void* out);
+int fie_pixels_in_u8_f32(fie_ctx* ctx, const uint8_t* src, int H, int W, int normalize, void* dst, int copies);
+int fie_pixels_out_f32_u8(fie_ctx* ctx, const void* src, int64_t ld_in, int H, int W, uint8_t* dst);
+int fie_latent_prep_f32(fie_ctx* ctx, const void* moments, const float* eps_post, const float* noise, int64_t HW,
+                        float scaling_factor, float sqrt_ab, float sqrt_1mab, float* latents_out, void* model_in,
+                        int copies);
+int fie_lcm_step_f32(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, float guidance, float* latents,
+                     const float* noise, int64_t HW, float sqrt_ab_t, float sqrt_1mab_t, float c_skip, float c_out,
+                     float sqrt_ab_prev, float sqrt_1mab_prev, void* model_in, int copies, float inv_scaling,
+                     void* decode_in);
+
 /* ---- tuning hook for micro-benchmarks: force the GEMM/conv tile (0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64).
  * Process-global; not part of the drop-in surface. */
 int fie_debug_force_tile(int tile);

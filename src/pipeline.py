@@ -58,22 +58,22 @@ class FastEditor:
         if not str(device).startswith("cuda"):
             raise RuntimeError(f"device={device!r}: the MI355X build runs the hot path in HIP kernels only "
                                "(the CPU restatement lives in oracle/ and is test infrastructure)")
-        if self.dtype != torch.float16:
-            raise NotImplementedError("fp32 (--full_precision / --quality_mode) HIP path is not built yet; "
-                                      "use the default fp16 path")
+        if self.dtype not in (torch.float16, torch.float32):
+            raise NotImplementedError(f"dtype {self.dtype}: the HIP path is built for float16 and float32")
         dev_index = torch.device(device).index
         if dev_index is None:
             dev_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
         if torch.cuda.is_available():
             torch.cuda.set_device(dev_index)      # the C-ABI launches go to the calling thread's current HIP device
-        ctx = hip.context(dev_index)
+        ctx = hip.context(dev_index, self.dtype)
         weights_dir = weights_dir or os.environ.get("FIE_WEIGHTS_DIR")
         log(f"Loading ControlNet (Canny) - {'FULL SIZE' if use_full_controlnet else 'small variant'}...")
-        log("Loading VAE (fp16-fix)...")
+        log("Loading VAE (fp32 for maximum quality)..." if self.dtype == torch.float32 else "Loading VAE (fp16-fix)...")
         toks = None
         if weights_dir:
             log(f"Loading weights from {weights_dir}")
-            cfgs, sds, toks = stack.directory_stack(weights_dir, model_name, use_full_controlnet)
+            cfgs, sds, toks = stack.directory_stack(weights_dir, model_name, use_full_controlnet,
+                                                         variant="fp16" if self.dtype == torch.float16 else None)
         else:
             log(f"No weights directory given: seeded synthetic weights (seed {seed_weights}) for preset "
                 f"{stack.stack_configs(model_name, use_full_controlnet)['unet']['name']}")
@@ -81,13 +81,13 @@ class FastEditor:
             if broadcast_weights and torch.distributed.is_available() and torch.distributed.is_initialized() \
                     and torch.distributed.get_world_size() > 1:
                 try:      # rank 0 generates, one bucketed RCCL broadcast over xGMI feeds the other ranks
-                    cfgs, sds = stack.broadcast_stack(model_name, use_full_controlnet, device=ctx.device, seed=seed_weights)
+                    cfgs, sds = stack.broadcast_stack(model_name, use_full_controlnet, device=ctx.device, dtype=self.dtype, seed=seed_weights)
                     log("Weights broadcast from rank 0")
                 except Exception as e:  # a broken fabric must not take the job down: every rank can regenerate from the seed
                     log(f"weight broadcast failed ({type(e).__name__}: {e}); regenerating locally from the seed")
                     cfgs = sds = None
             if sds is None:
-                cfgs, sds = stack.synthetic_stack(model_name, use_full_controlnet, device=ctx.device, seed=seed_weights)
+                cfgs, sds = stack.synthetic_stack(model_name, use_full_controlnet, device=ctx.device, dtype=self.dtype, seed=seed_weights)
         self.presets = {k: c["name"] for k, c in cfgs.items()}
         log("Setting LCM scheduler...")
         self.pipe = HipImg2ImgPipeline(ctx, cfgs, sds, tokenizers=toks, noise_dtype=noise_dtype or self.dtype)

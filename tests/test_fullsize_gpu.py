@@ -127,3 +127,34 @@ def test_lcm_step_identity_full_size(fie):
     mi = torch.empty(1, hw, 8, device=fie.device, dtype=torch.float16)
     fie.lcm_step(eps, 1, 1.0, lat, None, hw, 0.5, 0.866, 0.0, 1.0, 1.0, 0.0, mi, 1.0, None)
     assert torch.allclose(lat, ref / 0.5, rtol=1e-6)
+
+
+def test_full_size_fp16_vs_fp32_paths(big, fie):
+    """north_star tolerance at BASELINE size: the fp16 hot path against the exact-fp32 HIP path (same seeded weights, fp32
+    noise from a CPU generator, SSD-1B-A' + ControlNet-full, 1024x1024, 2 evals, CFG): SSIM >= 0.99 at the metric
+    resolution (512x512 LANCZOS, reference src/metrics.py:227-231) and at full resolution."""
+    import time
+    from PIL import Image
+    from fie_amd import hip, stack
+    from fie_amd.pipe import HipImg2ImgPipeline
+    from oracle import metrics
+    from test_pipeline_gpu import synth_image
+    ctx32 = hip.context(0, torch.float32)
+    cfgs, sds = stack.synthetic_stack("ssd-1b", True, device=fie.device, dtype=torch.float32)
+    p32 = HipImg2ImgPipeline(ctx32, cfgs, sds)
+    del sds
+    img = synth_image(123, 512).resize((1024, 1024), Image.LANCZOS)
+    ctrl = Image.fromarray(hip.canny_rgb(np.asarray(img)))
+    kw = dict(prompt="a slanted [rusty] mountain bicycle on the road in front of a building", negative_prompt="", image=img,
+              control_image=ctrl, strength=0.5, num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5)
+    big.use_graph = False
+    p32.use_graph = False
+    a = big(generator=torch.Generator("cpu").manual_seed(42), **kw).images[0]
+    t0 = time.time()
+    b = p32(generator=torch.Generator("cpu").manual_seed(42), **kw).images[0]
+    dt = time.time() - t0
+    s512, s1024 = metrics.ssim(a, b), metrics.ssim(a, b, size=None)
+    d = np.abs(np.asarray(a).astype(int) - np.asarray(b).astype(int))
+    print(f"fp16 vs fp32 HIP @1024^2: SSIM(512)={s512:.5f} SSIM(1024)={s1024:.5f} max|du8|={d.max()} mean|du8|={d.mean():.3f}; "
+          f"fp32 edit {dt:.2f}s")
+    assert s512 >= 0.99 and s1024 >= 0.99
