@@ -184,19 +184,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs a launcher with WORLD_SIZE={args.gpus} (torch.distributed.run)")
-    torch.cuda.set_device(local)
+    dev_index = local % torch.cuda.device_count()      # == local on a real N-GPU node; folds ranks in a one-GPU gloo rehearsal
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("FIE_DIST_BACKEND", "nccl")
+        kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
 
     import contextlib
     import io
     from src.pipeline import FastEditor
     from fie_amd import flops
     with contextlib.redirect_stdout(io.StringIO() if rank else sys.stderr):
-        editor = FastEditor(model_name=args.model, device=f"cuda:{local}" if world > 1 else "cuda",
+        editor = FastEditor(model_name=args.model, device=f"cuda:{dev_index}" if world > 1 else "cuda",
                             enable_cpu_offload=False, use_full_controlnet=args.controlnet == "full")
     pipe = editor.pipe
     cfgs = pipe.cfgs
@@ -250,7 +253,7 @@ def main():
     elapsed = timed_pass()
     per_rank = [elapsed]
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
         g = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(g, t)                      # C2: gather of per-rank timings (metrics) on every rank
         per_rank = [float(x.item()) for x in g]

@@ -22,11 +22,13 @@ def init(backend=None):
     """Initialise the default process group from the launcher's env (no-op for a single process)."""
     rank, local, world = env_world()
     if world > 1 and torch.cuda.is_available():
-        torch.cuda.set_device(local)          # every launch of this process (torch's and the HIP library's) targets its GPU
+        # every launch of this process (torch's and the HIP library's) targets its GPU; a rehearsal with more ranks than
+        # GPUs (gloo on a one-GPU box) folds the ranks onto the devices that exist
+        torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("FIE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local, world
@@ -52,7 +54,12 @@ def broadcast_state_dicts(sds, src=0, device=None, bucket_bytes=1 << 30):
             return
         dt = sds[bucket[0][0]][bucket[0][1]].dtype
         buf = torch.cat([sds[c][n].reshape(-1).to(device or sds[c][n].device) for c, n in bucket])
-        dist.broadcast(buf, src=src)
+        if dist.get_backend() == "gloo" and buf.is_cuda:      # gloo moves host memory: stage through the CPU
+            host = buf.cpu()
+            dist.broadcast(host, src=src)
+            buf.copy_(host)
+        else:
+            dist.broadcast(buf, src=src)
         off = 0
         for c, n in bucket:
             t = sds[c][n]

@@ -207,7 +207,8 @@ def main(argv=None):
     import contextlib
     import io
     with contextlib.redirect_stdout(sys.stdout if rank == 0 else io.StringIO()):
-        editor = FastEditor(model_name=args.model, device="cuda" if world == 1 else f"cuda:{local}",
+        import torch
+        editor = FastEditor(model_name=args.model, device="cuda" if world == 1 else f"cuda:{local % max(torch.cuda.device_count(), 1)}",
                             enable_cpu_offload=not args.no_cpu_offload, use_full_precision=args.full_precision,
                             use_full_controlnet=args.full_controlnet, weights_dir=args.weights_dir)
     if hasattr(editor, "pipe"):
