@@ -14,6 +14,8 @@ import argparse
 import csv
 import json
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")    # before HIP initialises; see fie_amd.py
 import sys
 import time
 
@@ -175,7 +177,7 @@ def main():
     ap.add_argument("--strength", type=float, default=0.5)
     ap.add_argument("--guidance", type=float, default=1.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=1, help="edits in flight per GPU (independent hipGraph slots on separate streams)")
+    ap.add_argument("--in-flight", type=int, default=2, help="edits in flight per GPU (independent hipGraph slots on separate streams)")
     ap.add_argument("--no-graph", action="store_true", help="issue the launches eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
@@ -227,7 +229,9 @@ def main():
         torch.cuda.synchronize()
 
     nfl = 1 if args.no_graph else max(1, args.in_flight)
-    streams = [torch.cuda.Stream() for _ in range(nfl)]
+    # ROCm keeps separate hardware queues per stream priority, so alternating priorities guarantees that two edits in
+    # flight never share one queue (same-priority streams are hashed onto 4 queues and may collide: measured 11.1 vs 13.8)
+    streams = [torch.cuda.Stream(priority=-(i % 2)) for i in range(nfl)]
 
     def run(job, s):
         if args.no_graph:
@@ -246,7 +250,7 @@ def main():
         return time.perf_counter() - t_
 
     single = None
-    if nfl > 1:                                          # reference point: one edit at a time on one stream
+    if nfl > 1:                                          # reference point: one edit at a time (forked two-stream graph)
         keep, nfl = nfl, 1
         single = timed_pass()
         nfl = keep
@@ -279,10 +283,47 @@ def main():
     image_tflops = fl["total"] / (sum(stage.values()) * 1e-3) / 1e12
 
     # ---- end-to-end (PIL in -> PIL out: LANCZOS, Canny, H2D, device, D2H) as run_batch.py:208-221 times it
-    t1 = time.perf_counter()
-    for s in range(2):
+    def edit_once():
         editor.edit(first[3], first[2], strength=args.strength, guidance_scale=args.guidance, seed=42)
-    e2e = (time.perf_counter() - t1) / 2
+
+    edit_once()                                          # first call: Canny workspace, PIL filter tables
+    marks = {}
+
+    def wrap(obj, name):
+        fn = getattr(obj, name)
+
+        def timed(*a, **k):
+            t_ = time.perf_counter()
+            r = fn(*a, **k)
+            marks[name] = marks.get(name, 0.0) + (time.perf_counter() - t_) * 1e3 / 4
+            return r
+        setattr(obj, name, timed)
+        return fn
+
+    saved = [(o, n, wrap(o, n)) for o, n in ((editor, "_canny_device"), (pipe, "prepare"), (pipe, "run_device_graphed"))]
+    t1 = time.perf_counter()
+    for s in range(4):
+        edit_once()
+    e2e = (time.perf_counter() - t1) / 4
+    for o, n, fn in saved:
+        setattr(o, n, fn)
+    log(f"e2e host ms/edit: { {k: round(v, 1) for k, v in marks.items()} } of {e2e * 1e3:.1f}")
+    e2e_nfl = None
+    if nfl > 1:                                          # the same through worker threads, as run_batch.py --in_flight does
+        from concurrent.futures import ThreadPoolExecutor
+        editor.set_in_flight(nfl)
+
+        def worker(slot, n):
+            editor.worker_slot(slot)
+            for _ in range(n):
+                edit_once()
+
+        with ThreadPoolExecutor(max_workers=nfl) as pool:
+            list(pool.map(lambda sl: worker(sl, 1), range(nfl)))          # capture the per-slot graphs
+            t1 = time.perf_counter()
+            list(pool.map(lambda sl: worker(sl, 4), range(nfl)))
+            e2e_nfl = (time.perf_counter() - t1) / (4 * nfl)
+        editor.set_in_flight(1)
     log(f"stage ms: { {k: round(v, 1) for k, v in stage.items()} }; e2e {e2e * 1e3:.1f} ms/image")
 
     if rank == 0:
@@ -305,6 +346,7 @@ def main():
             "stage_ms": {k: round(v, 2) for k, v in stage.items()},
             "image_tflops": round(image_tflops, 2),
             "e2e_images_per_sec": round(1.0 / e2e, 4),
+            "e2e_in_flight_images_per_sec": None if e2e_nfl is None else round(1.0 / e2e_nfl, 4),
             "per_rank_seconds": [round(x, 4) for x in per_rank],
             "single_stream_images_per_sec": round(args.steps * world / single, 4) if single else None,
         }

@@ -12,6 +12,8 @@ import argparse
 import csv
 import json
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")    # before HIP initialises; see fie_amd.py
 import sys
 
 import numpy as np

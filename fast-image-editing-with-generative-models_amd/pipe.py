@@ -3,6 +3,7 @@ StableDiffusionXLControlNetImg2ImgPipeline call at /root/reference/src/pipeline.
 (CLIP text, VAE encode, ControlNet + UNet evaluations, CFG + LCM step, VAE decode, pixel conversion) runs in the
 hand-written HIP kernels of csrc/ (call order: SURVEY.md 3.2 steps 1-9)."""
 import os
+import threading
 import types
 
 import numpy as np
@@ -39,6 +40,9 @@ class HipImg2ImgPipeline:
         self.use_graph = os.environ.get("FIE_NO_GRAPH", "0") != "1"
         self._graphs = {}
         self._side = None
+        self._slot_streams = {}
+        self.eager_lock = threading.RLock()
+        self.fork_streams = os.environ.get("FIE_NO_FORK", "0") != "1"
 
     # -- diffusers API surface the reference touches
     def set_progress_bar_config(self, **kw):          # run_batch.py:157-158
@@ -105,6 +109,12 @@ class HipImg2ImgPipeline:
             noises=[self._randn((1, 4, lh, lw), generator) for _ in range(n_noise)])
 
     def _side_stream(self):
+        """Second stream for the independent branches of one edit (CLIP beside the VAE encode, UNet encoder beside the
+        ControlNet trunk).  `fork_streams = False` keeps the whole edit on one stream.  Overlap between the branches
+        (and between edits in flight) needs the streams to land on different hardware queues: see GPU_MAX_HW_QUEUES in
+        fie_amd.py."""
+        if not self.fork_streams:
+            return torch.cuda.current_stream(self.ctx.device)
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.ctx.device)
         return self._side
@@ -189,24 +199,11 @@ class HipImg2ImgPipeline:
         The returned u8 image is the graph's static output buffer (consume it before the next replay).
         `slot` selects an independent graph instance (own static buffers / scratch) so that several edits can be in
         flight on different streams of one GPU."""
-        key = (job["hw"], job["nb"], tuple(st["t"] for st in job["steps"]), job["guidance"], job["cn_scale"], slot)
+        key = (job["hw"], job["nb"], tuple(st["t"] for st in job["steps"]), job["guidance"], job["cn_scale"], slot, self.fork_streams)
         entry = self._graphs.get(key)
         if entry is None:
-            static = dict(job)
-            for k in self._TENSOR_KEYS:
-                static[k] = job[k].clone()
-            static["noises"] = [n.clone() for n in job["noises"]]
-            static["t_dev"] = [t.clone() for t in job["t_dev"]]
-            timing, self.timing = self.timing, None
-            self.ctx.ws_tag = slot
-            self.run_device(static)                     # eager warm-up: lazy workspaces / function attributes
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self.run_device(static)
-            self.ctx.ws_tag = 0
-            self.timing = timing
-            entry = self._graphs[key] = (graph, static, out)
+            with self.eager_lock:                       # eager launches + capture go through the one C-ABI context
+                entry = self._graphs.get(key) or self._capture(key, job, slot)
         graph, static, out = entry
         if static is not job:
             for k in self._TENSOR_KEYS:
@@ -216,6 +213,25 @@ class HipImg2ImgPipeline:
         graph.replay()
         return out
 
+    def _capture(self, key, job, slot):
+        static = dict(job)
+        for k in self._TENSOR_KEYS:
+            static[k] = job[k].clone()
+        static["noises"] = [n.clone() for n in job["noises"]]
+        static["t_dev"] = [t.clone() for t in job["t_dev"]]
+        timing, self.timing = self.timing, None
+        self.ctx.ws_tag = slot
+        self.run_device(static)                     # eager warm-up: lazy workspaces / function attributes
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        # thread_local: other worker threads keep replaying / allocating on their own streams during this capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            out = self.run_device(static)
+        self.ctx.ws_tag = 0
+        self.timing = timing
+        self._graphs[key] = (graph, static, out)
+        return self._graphs[key]
+
     def stage_ms(self):
         """Per-stage device milliseconds of the last run_device() (needs `self.timing = []` before the call)."""
         torch.cuda.synchronize()
@@ -224,12 +240,35 @@ class HipImg2ImgPipeline:
             out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
         return out
 
+    def slot_stream(self, slot):
+        """Stream of graph slot `slot`.  Every slot, slot 0 included, owns a stream: replaying an edit's graph on the legacy
+        null stream costs +30 ms per edit once other streams exist in the process (measured, 92 vs 122 ms end to end).
+        Odd slots are high-priority: ROCm gives each priority its own hardware queues, so slots 0 and 1 can never be hashed
+        onto one queue (which would serialise the two edits)."""
+        if slot not in self._slot_streams:
+            self._slot_streams[slot] = torch.cuda.Stream(device=self.ctx.device, priority=-(slot % 2))
+        return self._slot_streams[slot]
+
     def __call__(self, prompt, negative_prompt="", image=None, control_image=None, strength=0.8,
                  num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5, generator=None,
-                 output_type="pil", **unused):
+                 output_type="pil", slot=0, **unused):
+        """`slot` (additive): independent hipGraph instance + stream, so that several calls may be in flight from different
+        host threads on one GPU (graph mode only)."""
+        if slot and not self.use_graph:
+            raise ValueError("slots > 0 need hipGraph replay (the eager path shares per-image state)")
+        caller, st = torch.cuda.current_stream(self.ctx.device), self.slot_stream(slot)
+        st.wait_stream(caller)                           # device-resident inputs may still be in flight on the caller's stream
+        with torch.cuda.stream(st):
+            out = self._call(prompt, negative_prompt, image, control_image, strength, num_inference_steps, guidance_scale,
+                             controlnet_conditioning_scale, generator, output_type, slot)
+        caller.wait_stream(st)
+        return out
+
+    def _call(self, prompt, negative_prompt, image, control_image, strength, num_inference_steps, guidance_scale,
+              controlnet_conditioning_scale, generator, output_type, slot):
         job = self.prepare(prompt, negative_prompt, image, control_image, strength, num_inference_steps,
                            guidance_scale, controlnet_conditioning_scale, generator)
-        out_u8 = self.run_device_graphed(job) if self.use_graph else self.run_device(job)
+        out_u8 = self.run_device_graphed(job, slot) if self.use_graph else self.run_device(job)
         if output_type == "latent":
             lh, lw = self.last_stats["latent_hw"]
             return types.SimpleNamespace(images=[self._latents.view(lh, lw, 4).clone()])

@@ -11,6 +11,8 @@ Additive flags (the reference has none of them): --strength, --weights_dir, --de
 import argparse
 import json
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")    # before HIP initialises; see fie_amd.py
 import sys
 import time
 
@@ -65,6 +67,8 @@ def build_parser():
     a("--strength", type=float, default=None, help="[additive] img2img strength (default: FastEditor.edit's 0.80)")
     a("--weights_dir", type=str, default=None, help="[additive] local diffusers-layout weights directory")
     a("--results_json", type=str, default=None, help="[additive] write the merged per-image rows + summary here")
+    a("--in_flight", type=int, default=1, help="[additive] edits in flight per GPU (worker threads, one hipGraph slot each); "
+                                                 "per-image times then overlap, throughput is the summary's wall-clock rate")
     return p
 
 
@@ -107,7 +111,30 @@ def save_comparison(path, source_img, edited_img, model, prompt):
 
 
 def process_shard(editor, entries, args, edited_dir, comparisons_dir, progress=None):
-    """The per-image loop (reference :176-261) over this rank's (index, image_id, entry) triples."""
+    """The per-image loop (reference :176-261) over this rank's (index, image_id, entry) triples; with --in_flight > 1 the
+    entries are dealt to worker threads (one graph slot each) and the per-worker results are merged."""
+    n = max(1, getattr(args, "in_flight", 1))
+    if n == 1:
+        return _process_entries(editor, entries, args, edited_dir, comparisons_dir, progress)
+    from concurrent.futures import ThreadPoolExecutor
+    editor.set_in_flight(n)
+
+    def work(slot):
+        editor.worker_slot(slot)
+        return _process_entries(editor, entries[slot::n], args, edited_dir, comparisons_dir, progress if slot == 0 else None)
+
+    with ThreadPoolExecutor(max_workers=n) as pool:
+        parts = list(pool.map(work, range(n)))
+    res = dict(processed=0, skipped=0, failed=0, total_time=0.0, rows=[])
+    for part in parts:
+        for k in ("processed", "skipped", "failed", "total_time"):
+            res[k] += part[k]
+        res["rows"] += part["rows"]
+    res["rows"].sort(key=lambda r: r["index"])
+    return res
+
+
+def _process_entries(editor, entries, args, edited_dir, comparisons_dir, progress=None):
     res = dict(processed=0, skipped=0, failed=0, total_time=0.0, rows=[])
     extra = {} if args.strength is None else {"strength": args.strength}
     for index, image_id, entry in (progress(entries) if progress else entries):

@@ -8,6 +8,8 @@ MI355X-native `FastEditor`.
 checkpoints that cannot be fetched offline and are reported as unavailable instead of silently skipped."""
 import argparse
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")    # before HIP initialises; see fie_amd.py
 import sys
 import time
 from datetime import datetime

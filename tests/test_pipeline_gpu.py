@@ -201,3 +201,22 @@ def test_run_batch_shard_end_to_end(fie, tmp_path, capsys):
     r2 = run_batch.process_shard(ed, entries, args, str(edited), str(out / "c"))
     assert (r2["processed"], r2["skipped"], r2["failed"]) == (0, 4, 2)
     assert "Invalid path" in capsys.readouterr().out
+
+
+def test_two_edits_in_flight_match_serial(fie):
+    """Worker threads on separate graph slots / streams produce exactly the serial results (--in_flight 2)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from src.pipeline import FastEditor
+    ed = FastEditor(model_name="tiny", enable_cpu_offload=False)
+    imgs = [synth_image(30 + i, 96) for i in range(6)]
+    serial = [np.asarray(ed.edit(im, f"a [toy] number {i}", seed=7, strength=0.5)) for i, im in enumerate(imgs)]
+    ed.set_in_flight(2)
+
+    def work(slot):
+        ed.worker_slot(slot)
+        return [(i, np.asarray(ed.edit(imgs[i], f"a [toy] number {i}", seed=7, strength=0.5))) for i in range(slot, 6, 2)]
+
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        got = dict(sum(pool.map(work, range(2)), []))
+    for i in range(6):
+        assert np.array_equal(got[i], serial[i]), i
