@@ -162,9 +162,14 @@ def time_dominant_kernel(pipe, nb, iters=20):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     tf = 2.0 * m * n * k / (us * 1e-6) / 1e12
+    # fabric-side bytes per launch from the rocprofv3 --pmc passes of this shape + epilogue (profiles/r01_dominant_kernel_summary.md,
+    # counter CSVs next to it): 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE.  Static: PMC cannot run inside the bench.
+    traffic_mb = 2 * 110460 * 1024 / 1e6 + 20480 * 1024 / 1e6 if (m, n, k) == (2048, 10240, 1280) else None
     return {"kernel": "gemm3_kernel<256,128,3,0,8> (FF1 GEGLU projection, 32x32 latents)", "shape": {"M": m, "N": n, "K": k},
             "avg_us": round(us, 2), "launches": iters, "achieved": round(tf, 1), "frac": round(tf / PEAK_F16_DENSE_TFLOPS, 4),
-            "algorithmic_gflop_per_launch": round(2.0 * m * n * k / 1e9, 2)}
+            "algorithmic_gflop_per_launch": round(2.0 * m * n * k / 1e9, 2),
+            "algorithmic_mb_per_launch": round((m * k + n * k + m * n // 2) * 2 / 1e6, 1),
+            "traffic_mb_per_launch": None if traffic_mb is None else round(traffic_mb, 1)}
 
 
 def main():
@@ -337,12 +342,19 @@ def main():
                        "unet_preset": cfgs["unet"]["name"], "controlnet_preset": cfgs["controlnet"]["name"],
                        "unet_evals": evals, "cfg_batch": nb, "parallelism": f"image-parallel x{world}", "launch": "eager" if args.no_graph else "hipGraph replay", "in_flight_per_gpu": nfl,
                        "tflop_per_image": round(fl["total"] / 1e12, 2)},
-            "roofline": {"bound": "mfma", "kernel": f"UNet forward ({cfgs['unet']['name']}, batch {nb}, random inputs): all launches between the "
-                                                    "HIP events bracketing unet.encode + unet.decode, issued alone on one stream",
-                         "achieved": round(unet_tflops, 2), "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(unet_tflops / PEAK_F16_DENSE_TFLOPS, 4), "traffic": None,
-                         "algorithmic_tflop": round(fl["unet"] * nb / 1e12, 3), "ms": round(unet_ms_per_fwd, 3),
-                         "dominant_kernel": dominant},
+            # the dominant kernel (largest share of device time in profiles/r01_final_bench_summary.md), HIP-event timed above;
+            # the whole UNet forward (every launch between the events bracketing unet.encode + unet.decode, alone on one
+            # stream) is priced against the same peak next to it
+            "roofline": {"bound": "mfma", "kernel": dominant["kernel"], "shape": dominant["shape"],
+                         "achieved": dominant["achieved"], "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dominant["frac"], "traffic": dominant["traffic_mb_per_launch"], "traffic_unit": "MB/launch (L2-miss side: "
+                         "2 x FETCH_SIZE + WRITE_SIZE; the operands fit the Infinity Cache)",
+                         "avg_us": dominant["avg_us"], "launches": dominant["launches"],
+                         "algorithmic_gflop_per_launch": dominant["algorithmic_gflop_per_launch"],
+                         "algorithmic_mb_per_launch": dominant["algorithmic_mb_per_launch"],
+                         "unet_forward": {"what": f"{cfgs['unet']['name']}, batch {nb}, random inputs", "achieved": round(unet_tflops, 2),
+                                          "frac": round(unet_tflops / PEAK_F16_DENSE_TFLOPS, 4),
+                                          "algorithmic_tflop": round(fl["unet"] * nb / 1e12, 3), "ms": round(unet_ms_per_fwd, 3)}},
             "stage_ms": {k: round(v, 2) for k, v in stage.items()},
             "image_tflops": round(image_tflops, 2),
             "e2e_images_per_sec": round(1.0 / e2e, 4),

@@ -235,10 +235,12 @@ __device__ __forceinline__ void wait_vm_barrier() {
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
     else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
@@ -908,12 +910,19 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     // Global->LDS bandwidth per CU (~30 B/clk measured) caps a tile at BM*BN/(BM+BN) FLOP per byte: 256x128 / 256x256
     // blocks (8 waves) where the grid still fills the chip, 128x64 otherwise, 64x64 for the smallest grids.
     const int64_t b62 = blocks(256, 128), b61 = blocks(256, 256);
+    // 160-wide tiles (N = k*160 everywhere in SD): one or two exact rounds of one block per CU on the 32x32 / 64x64-latent layers
+    auto rounds = [&](int64_t nb) { return (nb * 10 >= cus * 9 && nb <= cus) || (nb * 10 >= cus * 18 && nb <= 2 * cus); };
+    const bool n160 = ok3 && a.N % 160 == 0 && a.M <= 8192;
     int code;
     if (MODE == 1) {
         if (!ok3) code = a.Cin % BK == 0 ? 12 : 2;
+        else if (n160 && rounds(blocks(128, 160))) code = 92;
+        else if (n160 && blocks(64, 160) * 10 >= cus * 9 && blocks(64, 160) <= cus) code = 91;
         else if (a.N % 256 == 0 && b61 >= 2 * cus) code = 61;
         else if (a.N % 128 == 0 && b62 >= 150) code = 62;
         else code = 42;
+    } else if (n160 && a.K >= 2048 && a.N <= 1280 && rounds(blocks(128, 160))) {
+        code = 92;
     } else if (ok3 && a.N % 256 == 0 && a.K >= 2048 && b61 >= 2 * cus) {
         code = 61;
     } else if (ok3 && a.N % 128 == 0 && a.N >= 1536 && a.K >= 512 && b62 >= 200) {
@@ -930,8 +939,9 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
     if (ver == 6) { bm = 256; bn = tile == 1 ? 256 : (tile == 2 ? 128 : 320); }
     if (ver == 7) { bm = tile == 1 ? 128 : 256; bn = 128; }
+    if (ver == 9) { bm = tile == 1 ? 64 : 128; bn = 160; }                          // 91 = 64x160, 92 = 128x160 (4 waves, 3 stages): N = k*160 tiles
     if (ver == 8) { bm = 256; bn = 128; }                                           // 82 = halo-reuse conv, 16x16 patch x 128 channels                        // 71 = ping-pong 128x128, 72 = ping-pong 256x128   // 61 = 256x256 x2, 62 = 256x128 x3, 63 = 256x320 x2 stages (8 waves)
-    FIE_REQUIRE(ver <= 8 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5 || ver == 7) && tile == 3) && (ver != 8 || tile == 2),
+    FIE_REQUIRE(ver <= 9 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5 || ver == 7 || ver == 9) && tile == 3) && (ver != 8 || tile == 2),
                 "bad tile code %d", code);
     a.nbm = (a.M + bm - 1) / bm;
     a.nbn = (a.N + bn - 1) / bn;
@@ -958,7 +968,10 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
             if (g_force_tile) { fie_set_error("tile code %d: shape not eligible for the v3 kernel", code); return FIE_EINVAL; }
         } else {
             constexpr int M3 = MODE == 1 ? 2 : 0;
-            if (ver == 7) {
+            if (ver == 9) {
+                if (tile == 1) launch3_t<64, 160, 3, M3>(ctx, a, grid);
+                else launch3_t<128, 160, 3, M3>(ctx, a, grid);
+            } else if (ver == 7) {
                 if (tile == 1) launch4_t<128, 128, M3>(ctx, a, grid);
                 else launch4_t<256, 128, M3>(ctx, a, grid);
             } else if (ver == 6) {

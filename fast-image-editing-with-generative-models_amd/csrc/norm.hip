@@ -151,6 +151,142 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgsT<T> p) {
     }
 }
 
+// ---- single-pass GroupNorm for the small feature maps (32x32 / 64x64 latents): ONE block of 1024 threads owns one (image, group),
+// keeps the group's rows x cg values in registers (<= NV vectors of V channels per thread), reduces mean and then the CENTRED
+// second moment across the block, and writes the normalised (+SiLU) values -- one launch and one read of the tensor instead of
+// partial / finalize / apply (three launches, two reads; ~25 us -> ~8 us on a 2 x 1024 x 1280 map, which is pure launch latency).
+// A thread keeps one fixed channel piece (the block uses (1024 / npv) * npv threads), so gamma / beta live in registers.
+constexpr int GN1_THREADS = 1024;
+int g_gn_onepass = 1;      // tuning hook (fie_debug_gn_onepass): 0 = always the three-kernel path
+
+template <int ND>
+struct alignas(ND * 4) GnRaw { uint32_t d[ND]; };       // one vector of V channels as raw dwords (ND = V * sizeof(T) / 4)
+
+template <int V, typename T>
+__device__ __forceinline__ void gn_unpack(const uint32_t* d, float (&f)[V]) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) f[j] = __builtin_bit_cast(float, d[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < V / 2; ++j) {
+            const f16x2 h = __builtin_bit_cast(f16x2, d[j]);
+            f[2 * j] = (float)h[0];
+            f[2 * j + 1] = (float)h[1];
+        }
+    }
+}
+
+template <int V, int NV, typename T>
+__global__ __launch_bounds__(GN1_THREADS) void gn_onepass_kernel(GnArgsT<T> p) {
+    constexpr int ND = V * (int)sizeof(T) / 4;
+    __shared__ float red[2][GN1_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, g = blockIdx.x;
+    const int npv = p.cg / V;                           // vectors per row of this group
+    const int rstep = GN1_THREADS / npv;                // rows covered per pass
+    const bool live = tid < rstep * npv;
+    const int piece = tid % npv, rsub = tid / npv;
+    const int c0 = g * p.cg + piece * V;                // first channel of this thread's vector
+    const T* src; int ldx;
+    if (c0 < p.C1) { src = p.X1 + c0; ldx = p.C1; }
+    else { src = p.X2 + (c0 - p.C1); ldx = p.C2; }
+    src += ((int64_t)b * p.rows + rsub) * ldx;
+    const int64_t sstep = (int64_t)rstep * ldx;
+    GnRaw<ND> x[NV];                                    // kept in the storage type (80 f16 values = 40 VGPRs) ...
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (live && i * rstep + rsub < p.rows) {
+            x[i] = *reinterpret_cast<const GnRaw<ND>*>(src + i * sstep);
+            float f[V];
+            gn_unpack<V, T>(x[i].d, f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) sum += f[j];
+        }
+    }
+    auto block_sum = [&](float v, int slot) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[slot][wave] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < GN1_THREADS / 64; ++w) t += red[slot][w];
+        return t;
+    };
+    const float n = (float)p.rows * (float)p.cg;
+    const float mean = block_sum(sum, 0) / n;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (live && i * rstep + rsub < p.rows) {
+            // ... and re-converted in each phase: the empty asm stops the compiler from keeping the fp32 copies alive
+#pragma unroll
+            for (int k = 0; k < ND; ++k) asm volatile("" : "+v"(x[i].d[k]));
+            float f[V];
+            gn_unpack<V, T>(x[i].d, f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { const float d = f[j] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(block_sum(sq, 1) / n + p.eps);
+    if (!live) return;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        sc[j] = rstd * (float)p.gamma[c0 + j];
+        sh[j] = (float)p.beta[c0 + j] - mean * sc[j];
+    }
+    T* dst = p.Y + ((int64_t)b * p.rows + rsub) * p.C + c0;
+    const int64_t dstep = (int64_t)rstep * p.C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (i * rstep + rsub < p.rows) {
+#pragma unroll
+            for (int k = 0; k < ND; ++k) asm volatile("" : "+v"(x[i].d[k]));
+            float f[V];
+            gn_unpack<V, T>(x[i].d, f);
+            GnRaw<ND> o;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float y = f[j] * sc[j] + sh[j];
+                if (p.silu) y = sizeof(T) == 4 ? y / (1.0f + expf(-y)) : fie_silu(y);
+                f[j] = y;
+            }
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) o.d[j] = __builtin_bit_cast(uint32_t, f[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < V / 2; ++j) {
+                    f16x2 h;
+                    h[0] = (half_t)f[2 * j];
+                    h[1] = (half_t)f[2 * j + 1];
+                    o.d[j] = __builtin_bit_cast(uint32_t, h);
+                }
+            }
+            *reinterpret_cast<GnRaw<ND>*>(dst + i * dstep) = o;
+        }
+    }
+}
+
+// (V, NV) of the single-pass kernel for this shape, or false: the group's rows x cg values must fit NV vectors per thread
+template <typename T>
+bool gn_onepass(fie_ctx* ctx, const GnArgsT<T>& p, int B) {
+    if (p.C2 && p.C1 % p.cg != 0) return false;                          // a group never straddles the two sources
+    const int V = p.cg % 8 == 0 ? 8 : (p.cg % 4 == 0 ? 4 : 0);
+    if (!V || p.C1 % V || p.C2 % V || p.cg / V > GN1_THREADS) return false;
+    const int npv = p.cg / V, rstep = GN1_THREADS / npv;
+    const int64_t nv = (p.rows + rstep - 1) / rstep;
+    const dim3 grid((unsigned)p.G, (unsigned)B);
+    if (V == 8 && nv <= 5) hipLaunchKernelGGL((gn_onepass_kernel<8, 5, T>), grid, dim3(GN1_THREADS), 0, ctx->stream, p);
+    else if (V == 8 && nv <= 10) hipLaunchKernelGGL((gn_onepass_kernel<8, 10, T>), grid, dim3(GN1_THREADS), 0, ctx->stream, p);
+    else if (V == 4 && nv <= 20) hipLaunchKernelGGL((gn_onepass_kernel<4, 20, T>), grid, dim3(GN1_THREADS), 0, ctx->stream, p);
+    else return false;
+    return true;
+}
+
 // ---- LayerNorm: one wave per row, row kept in registers (C <= 4096)
 constexpr int LN_MAXV = 8;   // 8 chunks x 8 values per lane
 
@@ -238,6 +374,10 @@ int groupnorm_t(const char* who, fie_ctx* ctx, const void* X1, int C1, const voi
     p.gamma = (const T*)gamma; p.beta = (const T*)beta; p.eps = eps; p.silu = silu;
     int csplit = 1;
     FIE_REQUIRE(gn_plan(p, C, groups, rows_per_image, B, &csplit) == 0, "%s: cannot split C=%d (groups=%d) into aligned column blocks", who, C, groups);
+    if (g_gn_onepass && gn_onepass(ctx, p, B)) {
+        FIE_LAUNCH_CHECK();
+        return FIE_OK;
+    }
     p.partial = (float*)workspace;
     p.stats = p.partial + (int64_t)B * GN_MAX_CHUNKS * groups * 2;
     const dim3 grid((unsigned)p.nchunks, (unsigned)B, (unsigned)csplit);
@@ -292,3 +432,8 @@ int fie_layernorm_f32(fie_ctx* ctx, const void* X, int64_t ldx, void* Y, int64_t
 }
 
 }  // extern "C"
+
+extern "C" int fie_debug_gn_onepass(int enable) {
+    g_gn_onepass = enable;
+    return FIE_OK;
+}

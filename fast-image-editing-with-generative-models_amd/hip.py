@@ -54,6 +54,7 @@ SIGNATURES = {
     "fie_canny_rgb_device_u8": [_P, _P, _I, _I, _I, _I, _P, _P, _c.POINTER(_I)],
     "fie_debug_force_tile": [_I],
     "fie_debug_attn_variant": [_I],
+    "fie_debug_gn_onepass": [_I],
 }
 
 _lib = None

@@ -68,6 +68,9 @@ def test_norms_f32(f32):
     g, bt = rnd(96, seed=3), rnd(96, seed=4)
     ref = F.silu(F.group_norm(torch.cat([x1, x2], -1).transpose(1, 2), 32, g, bt, 1e-5).transpose(1, 2))
     assert rel_err(f32.groupnorm(x1.to(DEV), g.to(DEV), bt.to(DEV), 32, 1e-5, True, x2=x2.to(DEV)), ref) < 2e-5
+    x1, g, bt = rnd(2, 1024, 1280, seed=8) + 0.5, rnd(1280, seed=9), rnd(1280, seed=10)       # single-pass kernel shape
+    ref = F.silu(F.group_norm(x1.transpose(1, 2), 32, g, bt, 1e-5).transpose(1, 2))
+    assert rel_err(f32.groupnorm(x1.to(DEV), g.to(DEV), bt.to(DEV), 32, 1e-5, True), ref) < 2e-5
     x, g, bt = rnd(77, 768, seed=5) * 3 + 1, rnd(768, seed=6), rnd(768, seed=7)
     assert rel_err(f32.layernorm(x.to(DEV), g.to(DEV), bt.to(DEV)), F.layer_norm(x, (768,), g, bt, 1e-5)) < 2e-5
 

@@ -148,7 +148,11 @@ def test_attention_forced_rescale(fie):
 @pytest.mark.parametrize("b,rows,c1,c2,groups,silu", [(1, 1024, 320, 0, 32, True), (2, 256, 1280, 640, 32, True),
                                                       (1, 4096, 128, 0, 32, False), (1, 256, 1280, 1280, 32, True),
                                                       (1, 100, 64, 0, 32, True), (1, 65536, 128, 0, 32, True),
-                                                      (2, 1024, 640, 320, 32, True)])
+                                                      (2, 1024, 640, 320, 32, True),
+                                                      # single-pass kernel shapes (32x32 / 64x64 latent maps), ragged rows, concat
+                                                      (2, 1024, 1280, 0, 32, True), (2, 1024, 1280, 1280, 32, True),
+                                                      (2, 4096, 640, 0, 32, True), (1, 1000, 1280, 0, 32, False),
+                                                      (2, 1024, 640, 640, 32, True), (1, 2051, 640, 0, 32, True)])
 def test_groupnorm(fie, b, rows, c1, c2, groups, silu):
     x1 = rnd(b, rows, c1, seed=1) + 0.5
     x2 = rnd(b, rows, c2, seed=2) * 2 if c2 else None
@@ -160,6 +164,21 @@ def test_groupnorm(fie, b, rows, c1, c2, groups, silu):
         ref = F.silu(ref)
     out = fie.groupnorm(x1.to(DEV), gamma.to(DEV), beta.to(DEV), groups, 1e-5, silu, x2=x2.to(DEV) if c2 else None)
     assert rel_err(out, ref) < 3e-3
+
+
+@pytest.mark.parametrize("b,rows,c1,c2", [(2, 1024, 1280, 0), (2, 1024, 1280, 1280), (2, 4096, 640, 0), (1, 4096, 128, 0)])
+def test_groupnorm_single_pass_matches_three_kernel_path(fie, b, rows, c1, c2):
+    from fie_amd import hip
+    x1 = (rnd(b, rows, c1, seed=1) + 0.5).to(DEV)
+    x2 = (rnd(b, rows, c2, seed=2) * 2).to(DEV) if c2 else None
+    gamma, beta = rnd(c1 + c2, seed=3).to(DEV), rnd(c1 + c2, seed=4).to(DEV)
+    one = fie.groupnorm(x1, gamma, beta, 32, 1e-5, True, x2=x2)
+    try:
+        hip.lib().fie_debug_gn_onepass(0)
+        three = fie.groupnorm(x1, gamma, beta, 32, 1e-5, True, x2=x2)
+    finally:
+        hip.lib().fie_debug_gn_onepass(1)
+    assert rel_err(one, three.float()) < 1e-3
 
 
 @pytest.mark.parametrize("rows,c", [(4096, 640), (1024, 1280), (77, 768), (5, 64)])
@@ -221,7 +240,7 @@ def test_clip_embed(fie):
     assert rel_err(out, ref) < 2e-3
 
 
-@pytest.mark.parametrize("code", [1, 2, 3, 11, 12, 13, 22, 23, 31, 32, 41, 42, 43, 51, 52, 61, 62, 63, 71, 72, 82])
+@pytest.mark.parametrize("code", [1, 2, 3, 11, 12, 13, 22, 23, 31, 32, 41, 42, 43, 51, 52, 61, 62, 63, 71, 72, 82, 91, 92])
 def test_gemm_conv_every_kernel_variant(fie, code):
     """Every tile / pipeline variant behind the tuning hook gives the same results (v1 register-staged, v2 LDS-DMA ring)."""
     from fie_amd import hip

@@ -45,11 +45,14 @@ def run(which, tiles):
             a = torch.randn(m, k, device=DEV, dtype=torch.float16)
             w = ctx.pack_linear(torch.randn(n, k, device=DEV, dtype=torch.float16) * k ** -0.5)
             out = torch.empty(m, n, device=DEV, dtype=torch.float16)
-            res = []
+            res, ref = [], None
             for t in tiles:
                 hip.lib().fie_debug_force_tile(t)
                 dt = timeit(lambda: ctx.gemm(a, w, n, out=out))
-                res.append(f"t{t}: {dt * 1e6:8.1f} us {2 * m * n * k / dt / 1e12:7.1f} TF")
+                if ref is None:
+                    ref = out.float().clone()
+                err = float((out.float() - ref).abs().max())
+                res.append(f"t{t}: {dt * 1e6:8.1f} us {2 * m * n * k / dt / 1e12:7.1f} TF" + (f" !err {err:.3g}" if err > 1e-2 else ""))
             print(f"gemm M={m:6d} N={n:6d} K={k:6d}  " + "  ".join(res), flush=True)
             if n >= 5120:       # FF1 shapes: also with the production epilogue (bias + GEGLU)
                 wg = ctx.pack_linear(torch.randn(n, k, device=DEV, dtype=torch.float16) * k ** -0.5, geglu=True)

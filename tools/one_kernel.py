@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch ONE GEMM / conv shape a few times (for rocprofv3 --pmc runs).
-usage: tools/one_kernel.py gemm M N K code [iters] | conv B H W Cin Cout code [iters]"""
+usage: tools/one_kernel.py gemm M N K code [iters] [geglu] | conv B H W Cin Cout code [iters]"""
 import os
 import sys
 
@@ -18,9 +18,17 @@ if kind == "gemm":
     a = torch.randn(m, k, device="cuda", dtype=torch.float16)
     w = ctx.pack_linear(torch.randn(n, k, device="cuda", dtype=torch.float16) * k ** -0.5)
     out = torch.empty(m, n, device="cuda", dtype=torch.float16)
+    geglu = len(sys.argv) > 7 and sys.argv[7] == "geglu"       # the production FF1 epilogue: + bias, GEGLU
+    if geglu:
+        w = ctx.pack_linear(torch.randn(n, k, device="cuda", dtype=torch.float16) * k ** -0.5, geglu=True)
+        bias = torch.randn(n, device="cuda", dtype=torch.float16)
+        out = torch.empty(m, n // 2, device="cuda", dtype=torch.float16)
     hip.lib().fie_debug_force_tile(code)
     for _ in range(iters):
-        ctx.gemm(a, w, n, out=out)
+        if geglu:
+            ctx.gemm(a, w, n, out=out, bias=bias, act=hip.ACT_GEGLU)
+        else:
+            ctx.gemm(a, w, n, out=out)
 else:
     b, h, w_, cin, cout, code = map(int, sys.argv[2:8])
     iters = int(sys.argv[8]) if len(sys.argv) > 8 else 5
