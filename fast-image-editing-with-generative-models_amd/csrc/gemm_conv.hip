@@ -230,21 +230,17 @@ __device__ __attribute__((aligned(64))) half_t g_zero_page[64];
 
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
-    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-    else static_assert(N < 0, "add the vmcnt literal");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// wait until at most `later` K-steps' worth of loads (NP per step, issued after the stage about to be consumed) are in flight
+template <int NP, int ST>
+__device__ __forceinline__ void wait_stage(int later) {
+    if (ST >= 5 && later == 3) wait_vm_barrier<(ST >= 5 ? 3 : 0) * NP>();
+    else if (ST >= 4 && later == 2) wait_vm_barrier<(ST >= 4 ? 2 : 0) * NP>();
+    else if (ST >= 3 && later >= 1) wait_vm_barrier<(ST >= 3 ? 1 : 0) * NP>();
+    else wait_vm_barrier<0>();
 }
 
 __device__ __forceinline__ void glds16(const half_t* src, half_t* lds_dst) {
@@ -374,9 +370,7 @@ __global__ __launch_bounds__(NW * 64) void gemm2_kernel(GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         // groups still allowed in flight: the ones issued after stage kt's
         const int later = min(kt + ST - 2, nk - 1) - kt;
-        if (ST >= 4 && later == 2) wait_vm_barrier<2 * NP>();
-        else if (ST >= 3 && later >= 1) wait_vm_barrier<NP>();
-        else wait_vm_barrier<0>();
+        wait_stage<NP, ST>(later);
         if (kt + ST - 1 < nk) issue(kt + ST - 1, fill);
         const half_t* sa = smem + stage * STAGE;
         const half_t* sw = sa + BM * BK;
@@ -544,9 +538,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     int stage = 0, fill = ST - 1;
     for (int kt = 0; kt < nk; ++kt) {
         const int later = min(kt + ST - 2, nk - 1) - kt;
-        if (ST >= 4 && later == 2) wait_vm_barrier<2 * NP>();
-        else if (ST >= 3 && later >= 1) wait_vm_barrier<NP>();
-        else wait_vm_barrier<0>();
+        wait_stage<NP, ST>(later);
         const bool more = kt + ST - 1 < nk;
         const half_t* sa = smem + stage * STAGE;
         const half_t* sw = sa + BM * BK;
@@ -939,9 +931,9 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
     if (ver == 6) { bm = 256; bn = tile == 1 ? 256 : (tile == 2 ? 128 : 320); }
     if (ver == 7) { bm = tile == 1 ? 128 : 256; bn = 128; }
-    if (ver == 9) { bm = tile == 1 ? 64 : 128; bn = 160; }                          // 91 = 64x160, 92 = 128x160 (4 waves, 3 stages): N = k*160 tiles
+    if (ver == 9) { bm = tile == 2 ? 128 : 64; bn = 160; }                          // 91 = 64x160, 92 = 128x160 (4 waves, 3 stages), 93 = 64x160 x 5 stages
     if (ver == 8) { bm = 256; bn = 128; }                                           // 82 = halo-reuse conv, 16x16 patch x 128 channels                        // 71 = ping-pong 128x128, 72 = ping-pong 256x128   // 61 = 256x256 x2, 62 = 256x128 x3, 63 = 256x320 x2 stages (8 waves)
-    FIE_REQUIRE(ver <= 9 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5 || ver == 7 || ver == 9) && tile == 3) && (ver != 8 || tile == 2),
+    FIE_REQUIRE(ver <= 9 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5 || ver == 7) && tile == 3) && (ver != 8 || tile == 2),
                 "bad tile code %d", code);
     a.nbm = (a.M + bm - 1) / bm;
     a.nbn = (a.N + bn - 1) / bn;
@@ -970,7 +962,8 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
             constexpr int M3 = MODE == 1 ? 2 : 0;
             if (ver == 9) {
                 if (tile == 1) launch3_t<64, 160, 3, M3>(ctx, a, grid);
-                else launch3_t<128, 160, 3, M3>(ctx, a, grid);
+                else if (tile == 2) launch3_t<128, 160, 3, M3>(ctx, a, grid);
+                else launch3_t<64, 160, 5, M3>(ctx, a, grid);
             } else if (ver == 7) {
                 if (tile == 1) launch4_t<128, 128, M3>(ctx, a, grid);
                 else launch4_t<256, 128, M3>(ctx, a, grid);
