@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--guidance", type=float, default=1.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=2, help="edits in flight per GPU (independent hipGraph slots on separate streams)")
+    ap.add_argument("--batch", type=int, default=0, help="also time N images per device job (BASELINE config 'batch=8'); reported as "
+                                                         "batched_images_per_sec, never as `value`")
     ap.add_argument("--no-graph", action="store_true", help="issue the launches eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
@@ -272,6 +274,23 @@ def main():
     evals, nb = pipe.last_stats["unet_evals"], pipe.last_stats["cfg_batch"]
     value = args.steps * world / elapsed
 
+    batched = None
+    if args.batch > 1 and not args.no_graph:              # N images per job: UNet / ControlNet / CLIP at batch N x CFG
+        items_b = [items[(rank + s * world) % len(items)] for s in range(args.batch)]
+        imgs_b = [synth_item_image(int(it["image_id"]) % 100000 + s).resize((1024, 1024), Image.LANCZOS) for s, it in enumerate(items_b)]
+        ctrl_b = [editor.preprocess_image(im) for im in imgs_b]
+        gens = [torch.Generator(device="cpu").manual_seed(42) for _ in imgs_b]
+        jb = pipe.prepare_batch([it["editing_prompt"] for it in items_b], None, imgs_b, ctrl_b, args.strength, 4, args.guidance, 0.5, gens)
+        with torch.cuda.stream(streams[0]):
+            pipe.run_device_graphed(jb)
+            barrier()
+            t_ = time.perf_counter()
+            for _ in range(3):
+                pipe.run_device_graphed(jb)
+            barrier()
+        batched = 3 * args.batch * world / (time.perf_counter() - t_)
+        log(f"batch {args.batch}: {batched:.2f} images/s")
+
     # ---- roofline of the UNet forward, HIP-event timed on the launch stream (2 extra untimed-for-throughput passes)
     stage = {}
     for s in range(2):
@@ -357,6 +376,7 @@ def main():
                                           "algorithmic_tflop": round(fl["unet"] * nb / 1e12, 3), "ms": round(unet_ms_per_fwd, 3)}},
             "stage_ms": {k: round(v, 2) for k, v in stage.items()},
             "image_tflops": round(image_tflops, 2),
+            "batched_images_per_sec": None if batched is None else {"batch": args.batch, "value": round(batched, 4)},
             "e2e_images_per_sec": round(1.0 / e2e, 4),
             "e2e_in_flight_images_per_sec": None if e2e_nfl is None else round(1.0 / e2e_nfl, 4),
             "per_rank_seconds": [round(x, 4) for x in per_rank],

@@ -749,14 +749,17 @@ void launch4_t(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
     hipLaunchKernelGGL((gemm4_kernel<BM, BN, 3, MODE, 8>), grid, dim3(512), lds, ctx->stream, a);
 }
 
+int g_extra_lds = 0;    // tuning hook (fie_debug_extra_lds): pad the v3 kernels' dynamic LDS to lower their occupancy (A/B probe)
+
 template <int BM, int BN, int ST, int MODE, int NW = 4>
 void launch3_t(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
-    constexpr int lds = ST * (BM + BN) * BK * (int)sizeof(half_t);
-    static bool attr = false;
-    if (!attr) {
+    constexpr int lds0 = ST * (BM + BN) * BK * (int)sizeof(half_t);
+    const int lds = lds0 + g_extra_lds > 160 * 1024 ? 160 * 1024 : lds0 + g_extra_lds;
+    static int attr = 0;
+    if (attr < lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = true;
+        attr = lds;
     }
     hipLaunchKernelGGL((gemm3_kernel<BM, BN, ST, MODE, NW>), grid, dim3(NW * 64), lds, ctx->stream, a);
 }
@@ -1064,6 +1067,11 @@ extern "C" {
 int fie_debug_force_tile(int t) {
     g_force_order = t >= 1000 ? (t / 1000) - 1 : -1;      // 1000 + code: order 0, 2000 + code: order 1
     g_force_tile = t % 1000;
+    return FIE_OK;
+}
+
+int fie_debug_extra_lds(int bytes) {
+    g_extra_lds = bytes < 0 ? 0 : bytes;
     return FIE_OK;
 }
 

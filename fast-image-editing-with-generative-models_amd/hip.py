@@ -11,7 +11,7 @@ import subprocess
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libfie_hip.so")
+LIB_PATH = os.environ.get("FIE_LIB_PATH") or os.path.join(_CSRC, "libfie_hip.so")      # FIE_LIB_PATH: A/B builds of the same sources (tools/)
 
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU, ACT_GEGLU = 0, 1, 2, 3, 4
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "fie_debug_force_tile": [_I],
     "fie_debug_attn_variant": [_I],
     "fie_debug_gn_onepass": [_I],
+    "fie_debug_extra_lds": [_I],
 }
 
 _lib = None

@@ -108,6 +108,33 @@ class HipImg2ImgPipeline:
             t_dev=[torch.full((nb, 1), float(st["t"]), dtype=torch.float32).to(dev) for st in steps],
             noises=[self._randn((1, 4, lh, lw), generator) for _ in range(n_noise)])
 
+    def prepare_batch(self, prompts, negative_prompts, images, control_images, strength=0.8, num_inference_steps=4,
+                      guidance_scale=1.5, controlnet_conditioning_scale=0.5, generators=None):
+        """[additive] n independent edits as ONE device job (BASELINE config "batch=8"): the UNet / ControlNet / CLIP run
+        at batch n * nb, the VAE per image.  Rows are image-major ([img0 uncond, img0 cond, img1 uncond, ...]); each
+        image keeps its own generator, so image i of a batch draws exactly the noise a single call with that generator
+        draws (upstream: a list of generators, one per prompt)."""
+        n = len(prompts)
+        if not (n == len(images) == len(control_images)) or n == 0:
+            raise ValueError("prompts, images and control_images must be non-empty lists of one length")
+        negative_prompts = negative_prompts or [""] * n
+        generators = generators or [None] * n
+        jobs = [self._prepare(prompts[i], negative_prompts[i], images[i], control_images[i], strength, num_inference_steps,
+                              guidance_scale, controlnet_conditioning_scale, generators[i]) for i in range(n)]
+        if any(j["hw"] != jobs[0]["hw"] for j in jobs):
+            raise ValueError("all images of a batch must have one size")
+        nb, t77 = jobs[0]["nb"], jobs[0]["ids_g"].shape[1]
+        job = dict(jobs[0])
+        job["n"] = n
+        for k in ("ids_l", "ids_g", "time_ids"):
+            job[k] = torch.cat([j[k] for j in jobs], dim=0)
+        job["eos_rows"] = torch.cat([j["eos_rows"] + i * nb * t77 for i, j in enumerate(jobs)])
+        job["img_u8"] = torch.stack([j["img_u8"] for j in jobs])
+        job["ctl_u8"] = torch.stack([j["ctl_u8"] for j in jobs])
+        job["t_dev"] = [t.repeat(n, 1) for t in jobs[0]["t_dev"]]
+        job["noises"] = [z for j in jobs for z in j["noises"]]          # image-major: image i owns [i*k, (i+1)*k)
+        return job
+
     def _side_stream(self):
         """Second stream for the independent branches of one edit (CLIP beside the VAE encode, UNet encoder beside the
         ControlNet trunk).  `fork_streams = False` keeps the whole edit on one stream.  Overlap between the branches
@@ -143,25 +170,32 @@ class HipImg2ImgPipeline:
             pl, _ = self.clip_l(job["ids_l"])
             pg, pooled = self.clip_g(job["ids_g"], eos_rows=job["eos_rows"])
             text = torch.cat([pl, pg], dim=1)
-        text_len = text.shape[0] // nb
-        # 3. pixels
-        x_img = ctx.pixels_in(job["img_u8"], True)
-        cond = ctx.pixels_in(job["ctl_u8"], False, copies=nb)
-        # 5. prepare_latents: VAE posterior sample (draw #1), init noise (draw #2), add_noise
-        moments, _ = self.vae.encode_moments(x_img)
-        noises = list(job["noises"])
-        latents = torch.empty((hw, 4), device=dev, dtype=torch.float32)
-        model_in = torch.empty((nb, lh, lw, 8), device=dev, dtype=ctx.dtype)
+        n = job.get("n", 1)                               # images in this job (prepare_batch); rows are image-major
+        text_len = text.shape[0] // (n * nb)
+        # 3. pixels, 5. prepare_latents: VAE posterior sample (draw #1), init noise (draw #2), add_noise -- per image (the
+        # 1024^2 VAE tensors of a batch would cross the 2 GiB operand limit of the buffer-load kernels, and gain nothing)
+        imgs = job["img_u8"] if n > 1 else job["img_u8"][None]
+        ctls = job["ctl_u8"] if n > 1 else job["ctl_u8"][None]
+        per = len(job["noises"]) // n                     # noise tensors per image
+        latents = torch.empty((n, hw, 4), device=dev, dtype=torch.float32)
+        model_in = torch.empty((n * nb, lh, lw, 8), device=dev, dtype=ctx.dtype)
         sf = self.cfgs["vae"]["scaling_factor"]
-        ctx.latent_prep(moments, noises.pop(0), noises.pop(0), hw, sf, steps[0]["sqrt_ab"], steps[0]["sqrt_1mab"],
-                        latents, model_in)
+        conds = []
+        for i in range(n):
+            x_img = ctx.pixels_in(imgs[i], True)
+            conds.append(ctx.pixels_in(ctls[i], False, copies=nb))
+            moments, _ = self.vae.encode_moments(x_img)
+            ctx.latent_prep(moments, job["noises"][i * per], job["noises"][i * per + 1], hw, sf, steps[0]["sqrt_ab"],
+                            steps[0]["sqrt_1mab"], latents[i], model_in[i * nb:(i + 1) * nb])
+        cond = conds[0] if n == 1 else torch.cat(conds, dim=0)
+        next_noise = 2
         main.wait_stream(side)
         self._mark("clip+vae_encode")
         # 6. per-image invariants
         self.unet.begin_image(pooled, job["time_ids"])
         self.controlnet.begin_image(pooled, job["time_ids"])
         cond_emb = self.controlnet.cond_embedding(cond)
-        decode_in = torch.empty((1, lh, lw, 8), device=dev, dtype=ctx.dtype)
+        decode_in = torch.empty((n, lh, lw, 8), device=dev, dtype=ctx.dtype)
         self._mark("cond_embed")
         # 7. denoising loop
         for st, t_dev in zip(steps, job["t_dev"]):
@@ -179,15 +213,18 @@ class HipImg2ImgPipeline:
             skips, mid = self.controlnet.add_residuals(c_skips, c_mid, job["cn_scale"], skips, mid)
             eps = self.unet.decode(mid, skips, tb_u, text, text_len)
             self._mark("unet_dec")
-            z = None if st["last"] else noises.pop(0)
-            ctx.lcm_step(eps, nb, job["guidance"], latents, z, hw, st["sqrt_ab"], st["sqrt_1mab"], st["c_skip"],
-                         st["c_out"], st["sqrt_ab_prev"], st["sqrt_1mab_prev"], model_in, 1.0 / sf, decode_in)
+            for i in range(n):
+                z = None if st["last"] else job["noises"][i * per + next_noise]
+                ctx.lcm_step(eps[i * nb:(i + 1) * nb], nb, job["guidance"], latents[i], z, hw, st["sqrt_ab"], st["sqrt_1mab"],
+                             st["c_skip"], st["c_out"], st["sqrt_ab_prev"], st["sqrt_1mab_prev"], model_in[i * nb:(i + 1) * nb],
+                             1.0 / sf, decode_in[i:i + 1])
+            next_noise += 1
             self._mark("lcm_step")
         # 8-9. decode + postprocess
-        dec = self.vae.decode(decode_in)
-        out_u8 = ctx.pixels_out(dec)
+        outs = [ctx.pixels_out(self.vae.decode(decode_in[i:i + 1])) for i in range(n)]
+        out_u8 = outs[0] if n == 1 else torch.stack(outs)
         self._mark("vae_decode")
-        self.last_stats = dict(unet_evals=len(steps), cfg_batch=nb, latent_hw=(lh, lw))
+        self.last_stats = dict(unet_evals=len(steps), cfg_batch=nb, latent_hw=(lh, lw), images=n)
         self._latents = latents
         return out_u8
 
@@ -199,7 +236,8 @@ class HipImg2ImgPipeline:
         The returned u8 image is the graph's static output buffer (consume it before the next replay).
         `slot` selects an independent graph instance (own static buffers / scratch) so that several edits can be in
         flight on different streams of one GPU."""
-        key = (job["hw"], job["nb"], tuple(st["t"] for st in job["steps"]), job["guidance"], job["cn_scale"], slot, self.fork_streams)
+        key = (job["hw"], job["nb"], tuple(st["t"] for st in job["steps"]), job["guidance"], job["cn_scale"], slot, self.fork_streams,
+               job.get("n", 1))
         entry = self._graphs.get(key)
         if entry is None:
             with self.eager_lock:                       # eager launches + capture go through the one C-ABI context
@@ -266,6 +304,16 @@ class HipImg2ImgPipeline:
 
     def _call(self, prompt, negative_prompt, image, control_image, strength, num_inference_steps, guidance_scale,
               controlnet_conditioning_scale, generator, output_type, slot):
+        if isinstance(prompt, (list, tuple)):            # [additive] a batch: lists of prompts / images / generators
+            job = self.prepare_batch(list(prompt), negative_prompt if isinstance(negative_prompt, (list, tuple)) else None,
+                                     list(image), list(control_image), strength, num_inference_steps, guidance_scale,
+                                     controlnet_conditioning_scale, generator if isinstance(generator, (list, tuple)) else None)
+            out_u8 = self.run_device_graphed(job, slot) if self.use_graph else self.run_device(job)
+            arr = out_u8.cpu().numpy()
+            arr = arr[None] if arr.ndim == 3 else arr
+            if output_type == "np":
+                return types.SimpleNamespace(images=list(arr))
+            return types.SimpleNamespace(images=[Image.fromarray(a) for a in arr])
         job = self.prepare(prompt, negative_prompt, image, control_image, strength, num_inference_steps,
                            guidance_scale, controlnet_conditioning_scale, generator)
         out_u8 = self.run_device_graphed(job, slot) if self.use_graph else self.run_device(job)

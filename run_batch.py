@@ -67,6 +67,8 @@ def build_parser():
     a("--strength", type=float, default=None, help="[additive] img2img strength (default: FastEditor.edit's 0.80)")
     a("--weights_dir", type=str, default=None, help="[additive] local diffusers-layout weights directory")
     a("--results_json", type=str, default=None, help="[additive] write the merged per-image rows + summary here")
+    a("--batch_size", type=int, default=1, help="[additive] images per device job (UNet / ControlNet / CLIP batched; the reference "
+                                                  "is serial = 1); per-image time = job time / batch")
     a("--in_flight", type=int, default=1, help="[additive] edits in flight per GPU (worker threads, one hipGraph slot each); "
                                                  "per-image times then overlap, throughput is the summary's wall-clock rate")
     return p
@@ -137,6 +139,37 @@ def process_shard(editor, entries, args, edited_dir, comparisons_dir, progress=N
 def _process_entries(editor, entries, args, edited_dir, comparisons_dir, progress=None):
     res = dict(processed=0, skipped=0, failed=0, total_time=0.0, rows=[])
     extra = {} if args.strength is None else {"strength": args.strength}
+    bs = max(1, getattr(args, "batch_size", 1))
+    pending = []                                   # (index, image_id, rel, output_path, source_img, prompt) awaiting one device job
+
+    def flush():
+        if not pending:
+            return
+        kw = dict(num_inference_steps=args.steps, guidance_scale=args.guidance, controlnet_conditioning_scale=args.control_scale,
+                  canny_low_threshold=args.canny_low, canny_high_threshold=args.canny_high, seed=args.seed, **extra)
+        try:
+            t0 = time.time()
+            if bs == 1:
+                edited = [editor.edit(image=pending[0][4], prompt=pending[0][5], negative_prompt=args.negative_prompt, **kw)]
+            else:
+                edited = editor.edit_batch(images=[p[4] for p in pending], prompts=[p[5] for p in pending],
+                                           negative_prompts=[args.negative_prompt] * len(pending), **kw)
+            dt = (time.time() - t0) / len(pending)
+            for (index, image_id, rel, output_path, source_img, prompt), out in zip(pending, edited):
+                res["total_time"] += dt
+                out.save(output_path)
+                res["processed"] += 1
+                res["rows"].append(dict(index=index, image_id=image_id, image_path=rel, elapsed_s=dt))
+                if args.save_comparisons:
+                    save_comparison(os.path.join(comparisons_dir, rel.replace(".jpg", ".png")), source_img, out, args.model, prompt)
+                if res["processed"] % 10 == 0:
+                    editor.clear_memory()
+        except Exception as e:  # per-image isolation, as the reference does (a failing batch fails its images)
+            ids = ", ".join(str(p[1]) for p in pending)
+            print(f"\n      Error processing {ids} ({type(e).__name__}): {e}")
+            res["failed"] += len(pending)
+        pending.clear()
+
     for index, image_id, entry in (progress(entries) if progress else entries):
         try:
             rel = entry["image_path"]
@@ -154,30 +187,16 @@ def _process_entries(editor, entries, args, edited_dir, comparisons_dir, progres
             if not prompt:
                 res["failed"] += 1
                 continue
-            t0 = time.time()
-            edited = editor.edit(image=source_img, prompt=prompt, negative_prompt=args.negative_prompt,
-                                 num_inference_steps=args.steps, guidance_scale=args.guidance,
-                                 controlnet_conditioning_scale=args.control_scale, canny_low_threshold=args.canny_low,
-                                 canny_high_threshold=args.canny_high, seed=args.seed, **extra)
-            dt = time.time() - t0
-            res["total_time"] += dt
-            edited.save(output_path)
-            res["processed"] += 1
-            res["rows"].append(dict(index=index, image_id=image_id, image_path=rel, elapsed_s=dt))
-            if args.save_comparisons:
-                save_comparison(os.path.join(comparisons_dir, rel.replace(".jpg", ".png")), source_img, edited,
-                                args.model, prompt)
-            if res["processed"] % 10 == 0:
-                editor.clear_memory()
+            pending.append((index, image_id, rel, output_path, source_img, prompt))
+            if len(pending) == bs:
+                flush()
         except FileNotFoundError as e:
             print(f"\n      File not found for {image_id}: {e}")
             res["failed"] += 1
         except ValueError as e:
             print(f"\n      Invalid path for {image_id}: {e}")
             res["failed"] += 1
-        except Exception as e:  # per-image isolation, as the reference does
-            print(f"\n      Error processing {image_id} ({type(e).__name__}): {e}")
-            res["failed"] += 1
+    flush()
     return res
 
 

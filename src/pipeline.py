@@ -131,6 +131,27 @@ class FastEditor:
                          guidance_scale=guidance_scale, controlnet_conditioning_scale=controlnet_conditioning_scale,
                          generator=generator).images[0]
 
+    def edit_batch(self, images, prompts, negative_prompts=None, strength=0.80, num_inference_steps=4, guidance_scale=1.5,
+                   controlnet_conditioning_scale=0.5, canny_low_threshold=100, canny_high_threshold=200, seed=None):
+        """[additive] edit() for a list of images in ONE device job (UNet / ControlNet / CLIP at batch n x CFG; the
+        BASELINE "batch=8" configuration).  Every image gets its own generator seeded with `seed`, exactly as n serial
+        edit(..., seed=seed) calls would, so image i of the batch equals the serial result up to fp16 tiling effects."""
+        if len(images) != len(prompts) or not images:
+            raise ValueError("images and prompts must be non-empty lists of one length")
+        gens = None
+        if seed is not None:
+            gens = [torch.Generator(device=self.device).manual_seed(seed) for _ in images]
+        slot = getattr(self._tls, "slot", 0)
+        srcs, ctls = [], []
+        with self.pipe.eager_lock, torch.cuda.stream(self.pipe.slot_stream(slot)):
+            for im in images:
+                s_dev, c_dev = self._canny_device(im.resize((1024, 1024), Image.LANCZOS), canny_low_threshold, canny_high_threshold)
+                srcs.append(s_dev)
+                ctls.append(c_dev)
+        return self.pipe(slot=slot, prompt=list(prompts), negative_prompt=negative_prompts, image=srcs, control_image=ctls,
+                         strength=strength, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                         controlnet_conditioning_scale=controlnet_conditioning_scale, generator=gens).images
+
     def set_in_flight(self, n):
         """[additive] allow `n` edits in flight on this GPU: edit() may then be called from up to n worker threads (see
         `worker_slot`); each thread replays its own hipGraph slot on its own stream.  Measured on MI355X: 2 in flight =

@@ -97,7 +97,7 @@ def test_cli_flags_match_reference():
     for k, d in ref_batch.items():
         assert k in fb and fb[k][0] == d, k
     assert fb["--model"][2] == ("sdxl", "ssd-1b")
-    assert set(fb) - set(ref_batch) == {"--strength", "--weights_dir", "--results_json", "--in_flight"}
+    assert set(fb) - set(ref_batch) == {"--strength", "--weights_dir", "--results_json", "--in_flight", "--batch_size"}
     fs = _flags(run_single_image.build_parser())
     for k in ("--image", "--prompt", "--model", "--negative_prompt", "--steps", "--guidance", "--control_scale",
               "--canny_low", "--canny_high", "--seed", "--output_dir", "--no_cpu_offload", "--quality_mode",

@@ -220,3 +220,23 @@ def test_two_edits_in_flight_match_serial(fie):
         got = dict(sum(pool.map(work, range(2)), []))
     for i in range(6):
         assert np.array_equal(got[i], serial[i]), i
+
+
+def test_edit_batch_matches_serial_edits(fie):
+    """BASELINE config "batch=8": n images through one UNet / ControlNet / CLIP call give the serial results (per-image
+    generators, image-major rows); tolerance = fp16 tile / GroupNorm-chunk order effects only."""
+    from src.pipeline import FastEditor
+    from oracle import metrics
+    ed = FastEditor(model_name="tiny", enable_cpu_offload=False)
+    imgs = [synth_image(50 + i, 96) for i in range(3)]
+    prompts = [f"a [toy] number {i}" for i in range(3)]
+    serial = [np.asarray(ed.edit(im, p, seed=11, strength=0.5)) for im, p in zip(imgs, prompts)]
+    batch = [np.asarray(o) for o in ed.edit_batch(imgs, prompts, seed=11, strength=0.5)]
+    assert len(batch) == 3
+    for a, b in zip(serial, batch):
+        assert a.shape == b.shape == (1024, 1024, 3)
+        assert np.abs(a.astype(int) - b.astype(int)).max() <= 2
+        assert metrics.ssim(Image.fromarray(b), a, size=None) > 0.999
+    # a different prompt order must permute the outputs, not mix them
+    swapped = [np.asarray(o) for o in ed.edit_batch(imgs[::-1], prompts[::-1], seed=11, strength=0.5)]
+    assert np.abs(swapped[0].astype(int) - batch[2].astype(int)).max() <= 2
