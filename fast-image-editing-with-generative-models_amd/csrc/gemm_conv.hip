@@ -572,6 +572,367 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     epilogue<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// v6 = v3 with PRODUCER WAVES: the LDS-DMA pieces of a K-step are issued by NPW extra waves (one per SIMD) that do nothing
+// else, the NW compute waves only ds_read + MFMA.  Reason: issuing a 1 KiB DMA piece stalls the issuing wave for 60-185
+// cycles (guide, "LDS-DMA piece issue cost"); in v3 every compute wave pays that 6 times per K-step in front of its MFMAs.
+// Protocol (one raw barrier per K-step, all NW + NPW waves): producers wait for their own loads of stage kt (counted vmcnt),
+// everybody meets at the barrier, producers then refill the stage that was consumed in step kt - 1.
+template <int BM, int BN, int ST, int MODE, int NW, int NPW>
+__global__ __launch_bounds__((NW + NPW) * 64) void gemm6_kernel(GemmArgs p) {
+    constexpr int WGN = NW / 2;
+    constexpr int WM = BM / 2, WN = BN / WGN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int RA = BM / (8 * NPW), RW = BN / (8 * NPW);      // pieces per producer wave per K-step
+    constexpr int NP = RA + RW;
+    constexpr int STAGE = (BM + BN) * BK;
+    static_assert((ST - 1) * NP < 64, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) half_t smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (p.order ? bid % p.nbm : bid / p.nbn) * BM;
+    const int n0 = (p.order ? bid / p.nbm : bid % p.nbn) * BN;
+    const int nk = (p.K + BK - 1) / BK;
+
+    if (wave >= NW) {
+        // ------------------------------------------------------------------ producer
+        const int pw = wave - NW;
+        const int lr = lane >> 3;
+        const int c8 = (lane & 7) ^ lr;
+        const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)p.a1_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, (int)p.a2_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, (int)p.w_bytes, 0x00020000);
+        unsigned a_off1[RA], a_off2[RA], a_img[RA], w_off[RW];
+        int a_ih[RA], a_iw[RA];
+        bool a_ok[RA];
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = m0 + (pw + NPW * i) * 8 + lr;
+            a_ok[i] = m < p.M;
+            if (MODE == 2) {
+                const int hw = p.OH * p.OW;
+                const int b = m / hw, rem = m - b * hw;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                a_ih[i] = oh * p.stride - p.pt;
+                a_iw[i] = ow * p.stride - p.pl;
+                a_img[i] = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.Cin * 2u;
+                a_off1[i] = kOob;
+                a_off2[i] = 0;
+            } else {
+                a_off1[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda1 * 2u + c8 * 16u : kOob;
+                a_off2[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda2 * 2u + c8 * 16u : kOob;
+                a_ih[i] = a_iw[i] = 0;
+                a_img[i] = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) w_off[i] = (unsigned)(n0 + (pw + NPW * i) * 8 + lr) * (unsigned)p.ldw * 2u + c8 * 16u;
+        int cs = 0, ftap = 0;
+        const int csteps = MODE == 2 ? p.Cin / BK : 1;
+        const int k1_steps = p.K1 / BK;
+        const bool ktail = (p.K % BK) != 0;
+        auto issue = [&](int kt, int stage) {
+            half_t* sa = smem + stage * STAGE;
+            half_t* sw = sa + BM * BK;
+            if (MODE == 2) {
+                if (cs == 0) {
+                    const int ky = (ftap * 11) >> 5, kx = ftap - 3 * ky;
+                    const int hlim = p.H << p.ups, wlim = p.W << p.ups;
+#pragma unroll
+                    for (int i = 0; i < RA; ++i) {
+                        const int ih = a_ih[i] + ky, iw = a_iw[i] + kx;
+                        const bool ok = a_ok[i] && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+                        a_off1[i] = ok ? a_img[i] + (unsigned)((ih >> p.ups) * p.W + (iw >> p.ups)) * (unsigned)p.Cin * 2u + c8 * 16u : kOob;
+                    }
+                }
+                const unsigned so = (unsigned)cs * (BK * 2);
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (pw + NPW * i) * 512, a_off1[i], so);
+                if (++cs == csteps) { cs = 0; ++ftap; }
+            } else if (ktail && kt == nk - 1) {
+                const bool in_k = kt * BK + c8 * 8 < p.K;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (pw + NPW * i) * 512, in_k ? a_off1[i] : kOob, (unsigned)kt * (BK * 2));
+            } else if (kt < k1_steps || k1_steps == 0) {
+                const unsigned so = (unsigned)kt * (BK * 2);
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (pw + NPW * i) * 512, a_off1[i], so);
+            } else {
+                const unsigned so = (unsigned)(kt - k1_steps) * (BK * 2);
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a2, sa + (pw + NPW * i) * 512, a_off2[i], so);
+            }
+            const unsigned sow = (unsigned)kt * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) bload16(rs_w, sw + (pw + NPW * i) * 512, w_off[i], sow);
+        };
+#pragma unroll
+        for (int s_ = 0; s_ < ST - 1; ++s_)
+            if (s_ < nk) issue(s_, s_);
+        int fill = ST - 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_stage<NP, ST>(min(kt + ST - 2, nk - 1) - kt);
+            if (kt + ST - 1 < nk) issue(kt + ST - 1, fill);
+            fill = fill + 1 == ST ? 0 : fill + 1;
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- compute waves
+    const int wm = wave & 1, wn = wave >> 1;
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_barrier" ::: "memory");
+        const half_t* sa = smem + stage * STAGE;
+        const half_t* sw = sa + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 fw[FN], fa[FM];
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+                fw[i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * WN + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+                fa[j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + j * 16 + fr, kk * 4 + fq));
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        stage = stage + 1 == ST ? 0 : stage + 1;
+    }
+    epilogue<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int BM, int BN, int ST, int MODE, int NW, int NPW>
+void launch6_t(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
+    constexpr int lds = ST * (BM + BN) * BK * (int)sizeof(half_t);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm6_kernel<BM, BN, ST, MODE, NW, NPW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm6_kernel<BM, BN, ST, MODE, NW, NPW>), grid, dim3((NW + NPW) * 64), lds, ctx->stream, a);
+}
+
+// v5 = 256x256 tile, FOUR PHASES PER K-STEP with half-tile slot recycling (the guide's "256^2 8-phase" idea restated for this
+// data path).  v3's 256x256 build has room for two stages only, so every K-step ends on vmcnt(0): the DMA issued one step
+// ago must land before anything proceeds.  Here the two 64 KiB buffers are recycled at half-tile granularity instead:
+//   * a K-step is four phases of 16 MFMAs (one 64x32 quadrant of the wave's 128x64 tile each), each phase = its ds_reads,
+//     ONE half-tile of DMA (2 pieces per wave), the MFMAs, one raw s_barrier;
+//   * phase order (A0,W0) (A0,W1) (A1,W1) (A1,W0) with W0's fragments kept in registers: the step's W slots are dead after
+//     phase 2 and its A slots after phase 3, so phases 3/4 already refill the W slots with step t+2 while phases 1/2 fill the
+//     other buffer's A slots with step t+1;
+//   * every half-tile is therefore issued >= 3 phases before its first read and ONE counted wait per K-step (vmcnt(4): the
+//     two youngest half-tiles may still fly) + the phase-4 barrier orders it -- vmcnt never drains inside the loop.
+// RAW: a half-tile is read only after the issuing waves' counted wait and a barrier (end of phase 4).  WAR: a slot is refilled
+// only after a barrier that follows the phase holding its last ds_read (whose data the MFMAs of that phase consumed).
+template <int MODE>    // 0 = GEMM, 2 = conv with Cin % 64 == 0
+__global__ __launch_bounds__(512) void gemm5_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256, NW = 8, WM = 128, WN = 64, FM = 8, FN = 4;
+    constexpr int BUF = (BM + BN) * BK;          // halves per buffer: [A 256 rows | W 256 rows]
+    extern __shared__ __attribute__((aligned(16))) half_t smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (p.order ? bid % p.nbm : bid / p.nbn) * BM;
+    const int n0 = (p.order ? bid / p.nbm : bid % p.nbn) * BN;
+    const int lr = lane >> 3;
+    const int c8 = (lane & 7) ^ lr;
+
+    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)p.a1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, (int)p.a2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, (int)p.w_bytes, 0x00020000);
+
+    // piece i of this wave = rows (wave + 8 i) * 8 + lr of the 256-row tile: i = 0, 1 lie in half 0, i = 2, 3 in half 1
+    unsigned a_off1[4], a_off2[4], a_img[4], w_off[4];
+    int a_ih[4], a_iw[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + (wave + NW * i) * 8 + lr;
+        a_ok[i] = m < p.M;
+        if (MODE == 2) {
+            const int hw = p.OH * p.OW;
+            const int b = m / hw, rem = m - b * hw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            a_ih[i] = oh * p.stride - p.pt;
+            a_iw[i] = ow * p.stride - p.pl;
+            a_img[i] = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.Cin * 2u;
+            a_off1[i] = kOob;
+            a_off2[i] = 0;
+        } else {
+            a_off1[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda1 * 2u + c8 * 16u : kOob;
+            a_off2[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda2 * 2u + c8 * 16u : kOob;
+            a_ih[i] = a_iw[i] = 0;
+            a_img[i] = 0;
+        }
+        w_off[i] = (unsigned)(n0 + (wave + NW * i) * 8 + lr) * (unsigned)p.ldw * 2u + c8 * 16u;
+    }
+    const int csteps = MODE == 2 ? p.Cin / BK : 1;
+    const int k1_steps = p.K1 / BK;
+    const int nk = (p.K + BK - 1) / BK;
+    const bool ktail = (p.K % BK) != 0;
+
+    // A half `h` of K-step kt -> buffer kt & 1.  Conv: the tap of K-step kt is fixed when its half 0 is issued.
+    int a_cs = 0, a_tap = 0;           // channel block / tap of the NEXT K-step whose A half 0 will be issued
+    unsigned a_so = 0;                 // scalar offset of the K-step being issued (set with half 0, reused by half 1)
+    int a_src = 0;                     // GEMM: 0 = A1, 1 = A2, 2 = partial last step of A1
+    auto issue_a = [&](int kt, int h) {
+        half_t* dst = smem + (kt & 1) * BUF;
+        if (h == 0) {
+            if (MODE == 2) {
+                if (a_cs == 0) {
+                    const int ky = (a_tap * 11) >> 5, kx = a_tap - 3 * ky;
+                    const int hlim = p.H << p.ups, wlim = p.W << p.ups;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ih = a_ih[i] + ky, iw = a_iw[i] + kx;
+                        const bool ok = a_ok[i] && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+                        a_off1[i] = ok ? a_img[i] + (unsigned)((ih >> p.ups) * p.W + (iw >> p.ups)) * (unsigned)p.Cin * 2u + c8 * 16u : kOob;
+                    }
+                }
+                a_so = (unsigned)a_cs * (BK * 2);
+                if (++a_cs == csteps) { a_cs = 0; ++a_tap; }
+            } else if (ktail && kt == nk - 1) {
+                a_src = 2;
+                a_so = (unsigned)kt * (BK * 2);
+            } else if (kt < k1_steps || k1_steps == 0) {
+                a_src = 0;
+                a_so = (unsigned)kt * (BK * 2);
+            } else {
+                a_src = 1;
+                a_so = (unsigned)(kt - k1_steps) * (BK * 2);
+            }
+        }
+#pragma unroll
+        for (int i = 2 * h; i < 2 * h + 2; ++i) {
+            half_t* d = dst + (wave + NW * i) * 512;
+            if (MODE == 2 || a_src == 0) bload16(rs_a1, d, a_off1[i], a_so);
+            else if (a_src == 1) bload16(rs_a2, d, a_off2[i], a_so);
+            else bload16(rs_a1, d, (int)(a_so >> 1) + c8 * 8 < p.K ? a_off1[i] : kOob, a_so);   // K tail: columns >= K read as zero
+        }
+    };
+    auto issue_w = [&](int kt, int h) {
+        half_t* dst = smem + (kt & 1) * BUF + BM * BK;
+#pragma unroll
+        for (int i = 2 * h; i < 2 * h + 2; ++i) bload16(rs_w, dst + (wave + NW * i) * 512, w_off[i], (unsigned)kt * (BK * 2));
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: A(0), W(0) into buffer 0, W(1) into buffer 1 (A(1) follows in phases 1-2 of step 0)
+    issue_a(0, 0); issue_a(0, 1); issue_w(0, 0); issue_w(0, 1);
+    if (nk > 1) { issue_w(1, 0); issue_w(1, 1); wait_vm_barrier<4>(); }
+    else wait_vm_barrier<0>();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const half_t* sa = smem + (kt & 1) * BUF;
+        const half_t* sw = sa + BM * BK;
+        const bool next1 = kt + 1 < nk, next2 = kt + 2 < nk;
+        f16x8 fa[2][4], fw0[2][2], fw1[2][2];
+        // ---- phase 1: quadrant (A0, W0)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fw0[kk][i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * WN + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[kk][j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + j * 16 + fr, kk * 4 + fq));
+        }
+        if (next1) issue_a(kt + 1, 0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw0[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_barrier" ::: "memory");
+        // ---- phase 2: quadrant (A0, W1); last read of this step's W slots
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fw1[kk][i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * WN + 32 + i * 16 + fr, kk * 4 + fq));
+        if (next1) issue_a(kt + 1, 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw1[kk][i], fa[kk][j], acc[2 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_barrier" ::: "memory");
+        // ---- phase 3: quadrant (A1, W1); last read of this step's A slots; the W slots are free: refill with step kt + 2
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[kk][j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + 64 + j * 16 + fr, kk * 4 + fq));
+        if (next2) issue_w(kt + 2, 0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw1[kk][i], fa[kk][j], acc[2 + i][4 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_barrier" ::: "memory");
+        // ---- phase 4: quadrant (A1, W0) from registers; then the step's one counted wait
+        if (next2) issue_w(kt + 2, 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw0[kk][i], fa[kk][j], acc[i][4 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (next2) wait_vm_barrier<4>();      // A(kt+1) and W(kt+1) have landed; W(kt+2) may still be in flight
+        else wait_vm_barrier<0>();
+    }
+    epilogue<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int MODE>
+void launch5_t(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
+    constexpr int lds = 2 * 512 * BK * (int)sizeof(half_t);      // 128 KiB
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm5_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm5_kernel<MODE>), grid, dim3(512), lds, ctx->stream, a);
+}
+
 // v4 = v3's data path with a PING-PONG schedule: the block's 8 waves form two groups of 4 (one wave per SIMD each).  A K-step
 // is split into a load phase (LDS-DMA issue for step kt+2, then ALL fragment ds_reads of step kt into registers) and an
 // MFMA phase (the 2 x FN x FM MFMAs of step kt), each closed by a raw s_barrier; group 1 runs one barrier behind group 0, so
@@ -908,14 +1269,24 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     // 160-wide tiles (N = k*160 everywhere in SD): one or two exact rounds of one block per CU on the 32x32 / 64x64-latent layers
     auto rounds = [&](int64_t nb) { return (nb * 10 >= cus * 9 && nb <= cus) || (nb * 10 >= cus * 18 && nb <= 2 * cus); };
     const bool n160 = ok3 && a.N % 160 == 0 && a.M <= 8192;
+    // producer-wave kernels (gemm6, codes 65-69: the LDS-DMA issue moved off the MFMA waves) win where a CU holds one block
+    // and K is long: 32x32-latent convs and FF2 (128x128, <= 1 block per CU), 64x64-latent convs (256x128), 77-token GEMMs (64x64)
+    const int64_t b66 = blocks(128, 128);
     int code;
     if (MODE == 1) {
         if (!ok3) code = a.Cin % BK == 0 ? 12 : 2;
+        else if (a.N % 128 == 0 && b66 * 2 >= cus && b66 <= cus) code = 66;
+        else if (a.N % 128 == 0 && a.K >= 8192 && b66 <= cus * 5 / 2) code = 66;
+        else if (a.N % 128 == 0 && b62 * 2 >= cus && b62 <= cus) code = 65;
         else if (n160 && rounds(blocks(128, 160))) code = 92;
         else if (n160 && blocks(64, 160) * 10 >= cus * 9 && blocks(64, 160) <= cus) code = 91;
         else if (a.N % 256 == 0 && b61 >= 2 * cus) code = 61;
         else if (a.N % 128 == 0 && b62 >= 150) code = 62;
         else code = 42;
+    } else if (ok3 && a.M <= 256 && a.K >= 1024) {
+        code = 69;
+    } else if (ok3 && a.N % 128 == 0 && a.K >= 1024 && b66 * 2 >= cus && b66 <= cus) {
+        code = 66;
     } else if (n160 && a.K >= 2048 && a.N <= 1280 && rounds(blocks(128, 160))) {
         code = 92;
     } else if (ok3 && a.N % 256 == 0 && a.K >= 2048 && b61 >= 2 * cus) {
@@ -932,11 +1303,14 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     if (g_force_tile) code = g_force_tile;
     const int tile = code % 10, ver = code / 10;
     int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
-    if (ver == 6) { bm = 256; bn = tile == 1 ? 256 : (tile == 2 ? 128 : 320); }
+    if (ver == 6) {      // 61-63 v3 8-wave tiles, 64 four-phase 256x256, 65-69 producer-wave kernels (gemm6)
+        static const int bms[10] = {0, 256, 256, 256, 256, 256, 128, 128, 128, 64}, bns[10] = {0, 256, 128, 320, 256, 128, 128, 64, 128, 64};
+        bm = bms[tile]; bn = bns[tile];
+    }           // 64 = 256x256, four phases per K-step (gemm5)
     if (ver == 7) { bm = tile == 1 ? 128 : 256; bn = 128; }
     if (ver == 9) { bm = tile == 2 ? 128 : 64; bn = 160; }                          // 91 = 64x160, 92 = 128x160 (4 waves, 3 stages), 93 = 64x160 x 5 stages
     if (ver == 8) { bm = 256; bn = 128; }                                           // 82 = halo-reuse conv, 16x16 patch x 128 channels                        // 71 = ping-pong 128x128, 72 = ping-pong 256x128   // 61 = 256x256 x2, 62 = 256x128 x3, 63 = 256x320 x2 stages (8 waves)
-    FIE_REQUIRE(ver <= 9 && tile >= 1 && tile <= 3 && !((ver == 3 || ver == 5 || ver == 7) && tile == 3) && (ver != 8 || tile == 2),
+    FIE_REQUIRE(ver <= 9 && tile >= 1 && (tile <= 3 || ver == 6) && !((ver == 3 || ver == 5 || ver == 7) && tile == 3) && (ver != 8 || tile == 2),
                 "bad tile code %d", code);
     a.nbm = (a.M + bm - 1) / bm;
     a.nbn = (a.N + bn - 1) / bn;
@@ -971,7 +1345,13 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
                 if (tile == 1) launch4_t<128, 128, M3>(ctx, a, grid);
                 else launch4_t<256, 128, M3>(ctx, a, grid);
             } else if (ver == 6) {
-                if (tile == 1) launch3_t<256, 256, 2, M3, 8>(ctx, a, grid);
+                if (tile == 4) launch5_t<M3>(ctx, a, grid);
+                else if (tile == 5) launch6_t<256, 128, 3, M3, 8, 4>(ctx, a, grid);
+                else if (tile == 6) launch6_t<128, 128, 3, M3, 8, 4>(ctx, a, grid);
+                else if (tile == 7) launch6_t<128, 64, 3, M3, 4, 4>(ctx, a, grid);
+                else if (tile == 8) launch6_t<128, 128, 3, M3, 4, 4>(ctx, a, grid);
+                else if (tile == 9) launch6_t<64, 64, 3, M3, 4, 4>(ctx, a, grid);
+                else if (tile == 1) launch3_t<256, 256, 2, M3, 8>(ctx, a, grid);
                 else if (tile == 2) launch3_t<256, 128, 3, M3, 8>(ctx, a, grid);
                 else launch3_t<256, 320, 2, M3, 8>(ctx, a, grid);
             } else if (ver == 4) {

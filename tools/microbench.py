@@ -29,7 +29,10 @@ def timeit(fn, iters=20, warm=3):
 
 GEMMS = [(8192, 1920, 640), (4096, 5120, 640), (1024, 10240, 1280), (8192, 640, 640), (8192, 5120, 640), (8192, 640, 2560),
          (2048, 3840, 1280), (2048, 1280, 1280), (2048, 10240, 1280), (2048, 1280, 5120),
-         (154, 2560, 2048), (32768, 320, 320), (16384, 1536, 512), (4096, 4096, 4096)]
+         (154, 2560, 2048), (32768, 320, 320), (16384, 1536, 512), (4096, 4096, 4096),
+         # 77-token shapes (CLIP-L / bigG at CFG batch 2, cross-attention K/V)
+         (154, 1280, 1280), (154, 3840, 1280), (154, 5120, 1280), (154, 1280, 5120), (154, 2304, 768), (154, 3072, 768), (154, 768, 3072),
+         (154, 1280, 2048), (2, 1280, 1280)]
 CONVS = [  # b, h, w, cin, cout, stride, ups
     (2, 128, 128, 320, 320, 1, 0), (2, 128, 128, 640, 320, 1, 0), (2, 64, 64, 640, 640, 1, 0), (2, 64, 64, 1280, 640, 1, 0),
     (2, 32, 32, 1280, 1280, 1, 0), (2, 32, 32, 2560, 1280, 1, 0), (2, 32, 32, 1280, 1280, 1, 1),
