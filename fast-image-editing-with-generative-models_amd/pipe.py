@@ -41,6 +41,7 @@ class HipImg2ImgPipeline:
         self._graphs = {}
         self._side = None
         self._slot_streams = {}
+        self._host_out = {}
         self.eager_lock = threading.RLock()
         self.fork_streams = os.environ.get("FIE_NO_FORK", "0") != "1"
 
@@ -123,6 +124,8 @@ class HipImg2ImgPipeline:
                               guidance_scale, controlnet_conditioning_scale, generators[i]) for i in range(n)]
         if any(j["hw"] != jobs[0]["hw"] for j in jobs):
             raise ValueError("all images of a batch must have one size")
+        if n == 1:
+            return jobs[0]                                # the single-image job (and its graph)
         nb, t77 = jobs[0]["nb"], jobs[0]["ids_g"].shape[1]
         job = dict(jobs[0])
         job["n"] = n
@@ -302,6 +305,17 @@ class HipImg2ImgPipeline:
         caller.wait_stream(st)
         return out
 
+    def _to_host(self, out_u8, slot):
+        """D2H of the u8 result through a pinned staging buffer of the slot (a pageable `.cpu()` costs ~3x as much), then one
+        host memcpy so the caller owns its array.  Synchronises the current stream only."""
+        key = (slot, tuple(out_u8.shape))
+        host = self._host_out.get(key)
+        if host is None:
+            host = self._host_out[key] = torch.empty(out_u8.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(out_u8, non_blocking=True)
+        torch.cuda.current_stream(self.ctx.device).synchronize()
+        return host.numpy().copy()
+
     def _call(self, prompt, negative_prompt, image, control_image, strength, num_inference_steps, guidance_scale,
               controlnet_conditioning_scale, generator, output_type, slot):
         if isinstance(prompt, (list, tuple)):            # [additive] a batch: lists of prompts / images / generators
@@ -309,7 +323,7 @@ class HipImg2ImgPipeline:
                                      list(image), list(control_image), strength, num_inference_steps, guidance_scale,
                                      controlnet_conditioning_scale, generator if isinstance(generator, (list, tuple)) else None)
             out_u8 = self.run_device_graphed(job, slot) if self.use_graph else self.run_device(job)
-            arr = out_u8.cpu().numpy()
+            arr = self._to_host(out_u8, slot)
             arr = arr[None] if arr.ndim == 3 else arr
             if output_type == "np":
                 return types.SimpleNamespace(images=list(arr))
@@ -320,7 +334,7 @@ class HipImg2ImgPipeline:
         if output_type == "latent":
             lh, lw = self.last_stats["latent_hw"]
             return types.SimpleNamespace(images=[self._latents.view(lh, lw, 4).clone()])
-        arr = out_u8.cpu().numpy()                     # device -> host sync, as `.images[0]` implies upstream
+        arr = self._to_host(out_u8, slot)              # device -> host sync, as `.images[0]` implies upstream
         if output_type == "np":
             return types.SimpleNamespace(images=[arr])
         return types.SimpleNamespace(images=[Image.fromarray(arr)])

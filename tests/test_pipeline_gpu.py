@@ -240,3 +240,33 @@ def test_edit_batch_matches_serial_edits(fie):
     # a different prompt order must permute the outputs, not mix them
     swapped = [np.asarray(o) for o in ed.edit_batch(imgs[::-1], prompts[::-1], seed=11, strength=0.5)]
     assert np.abs(swapped[0].astype(int) - batch[2].astype(int)).max() <= 2
+
+
+def test_run_batch_in_flight_and_batched_match_serial(fie, tmp_path):
+    """run_batch --in_flight 2 (worker threads) and --batch_size 2 (one device job per two images) write the same images as
+    the serial loop, with the same counters."""
+    import run_batch
+    from src.pipeline import FastEditor
+    src = tmp_path / "src"
+    mapping = {}
+    for i in range(5):
+        rel = f"{i}_cat/{i:012d}.png"
+        (src / f"{i}_cat").mkdir(parents=True)
+        synth_image(70 + i, 96).save(src / rel)
+        mapping[f"{i:012d}"] = {"image_path": rel, "editing_prompt": f"a [green] thing {i}", "editing_type_id": str(i)}
+    mapping["nosrc"] = {"image_path": "9_cat/none.png", "editing_prompt": "x", "editing_type_id": "9"}
+    entries = [(i, k, e) for i, (k, e) in enumerate(mapping.items())]
+    ed = FastEditor(model_name="tiny", enable_cpu_offload=False)
+    outs = {}
+    for tag, extra in (("serial", []), ("threads", ["--in_flight", "2"]), ("batched", ["--batch_size", "2"])):
+        out = tmp_path / tag
+        args = run_batch.build_parser().parse_args(["--source_dir", str(src), "--output_dir", str(out), "--seed", "42",
+                                                    "--strength", "0.5"] + extra)
+        r = run_batch.process_shard(ed, entries, args, str(out / "e"), str(out / "c"))
+        ed.set_in_flight(1)
+        assert (r["processed"], r["skipped"], r["failed"]) == (5, 0, 1), tag
+        assert [row["index"] for row in r["rows"]] == [0, 1, 2, 3, 4]
+        outs[tag] = [np.asarray(Image.open(out / "e" / f"{i}_cat/{i:012d}.png")).astype(int) for i in range(5)]
+    for i in range(5):
+        assert np.array_equal(outs["threads"][i], outs["serial"][i])
+        assert np.abs(outs["batched"][i] - outs["serial"][i]).max() <= 2
