@@ -108,7 +108,7 @@ def test_full_size_determinism_graph_and_eval_count(big):
         outs.append(np.asarray(big(prompt="a [red] house", negative_prompt="", image=img, control_image=ctrl, strength=0.5,
                                    num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5,
                                    generator=torch.Generator("cpu").manual_seed(42)).images[0]))
-        assert big.last_stats == dict(unet_evals=2, cfg_batch=2, latent_hw=(128, 128))
+        assert big.last_stats == dict(unet_evals=2, cfg_batch=2, latent_hw=(128, 128), images=1)
     assert outs[0].shape == (1024, 1024, 3) and 5 < outs[0].std()
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
     for strength, evals in ((1.0, 4), (0.8, 3), (0.3, 1)):
