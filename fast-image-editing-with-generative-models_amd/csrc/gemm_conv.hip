@@ -12,6 +12,8 @@
 // LDS: two buffers of (BM + BN) rows x 128 B, 16-byte chunks XOR-swizzled by (row & 7) so that the
 // ds_read_b128 fragment reads of 16 different rows spread over the banks.  Global->LDS goes through registers
 // (the conv gather needs per-lane zero fill), issued one K-step ahead of the MFMAs that consume it.
+#include <cstdio>
+#include <cstdlib>
 #include "fie_internal.h"
 
 namespace {
@@ -1249,6 +1251,11 @@ void launch_halo(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
     hipLaunchKernelGGL((conv_halo_kernel<BN>), grid, dim3(512), lds, ctx->stream, a);
 }
 
+// tuning hook (fie_debug_tile_override): per-shape tile codes for whole-pipeline A/B runs, "mode,M,N,K=code;..." (mode 0 GEMM, 1 conv)
+struct TileOverride { int mode, M, N, K, code; };
+TileOverride g_overrides[32];
+int g_n_overrides = 0;
+
 int g_force_order = -1;  // tuning hook: -1 = estimate, 0 / 1 = force the tile order
 int g_force_tile = 0;   // tuning hook (fie_debug_force_tile): 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64
 
@@ -1268,24 +1275,26 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     const int64_t b62 = blocks(256, 128), b61 = blocks(256, 256);
     // 160-wide tiles (N = k*160 everywhere in SD): one or two exact rounds of one block per CU on the 32x32 / 64x64-latent layers
     auto rounds = [&](int64_t nb) { return (nb * 10 >= cus * 9 && nb <= cus) || (nb * 10 >= cus * 18 && nb <= 2 * cus); };
-    const bool n160 = ok3 && a.N % 160 == 0 && a.M <= 8192;
+    static const bool no_160 = getenv("FIE_160_TILES") == nullptr;              // off by default: neutral in the real pipeline
+    const bool n160 = !no_160 && ok3 && a.N % 160 == 0 && a.M <= 8192;
     // producer-wave kernels (gemm6, codes 65-69: the LDS-DMA issue moved off the MFMA waves) win where a CU holds one block
     // and K is long: 32x32-latent convs and FF2 (128x128, <= 1 block per CU), 64x64-latent convs (256x128), 77-token GEMMs (64x64)
     const int64_t b66 = blocks(128, 128);
+    static const bool no_producer = getenv("FIE_PRODUCER_TILES") == nullptr;   // off by default: +2.5 % UNet time in the real pipeline (cold weights), see DESIGN.md
     int code;
     if (MODE == 1) {
         if (!ok3) code = a.Cin % BK == 0 ? 12 : 2;
-        else if (a.N % 128 == 0 && b66 * 2 >= cus && b66 <= cus) code = 66;
-        else if (a.N % 128 == 0 && a.K >= 8192 && b66 <= cus * 5 / 2) code = 66;
-        else if (a.N % 128 == 0 && b62 * 2 >= cus && b62 <= cus) code = 65;
+        else if (!no_producer && a.N % 128 == 0 && b66 * 2 >= cus && b66 <= cus) code = 66;
+        else if (!no_producer && a.N % 128 == 0 && a.K >= 8192 && b66 <= cus * 5 / 2) code = 66;
+        else if (!no_producer && a.N % 128 == 0 && b62 * 2 >= cus && b62 <= cus) code = 65;
         else if (n160 && rounds(blocks(128, 160))) code = 92;
         else if (n160 && blocks(64, 160) * 10 >= cus * 9 && blocks(64, 160) <= cus) code = 91;
         else if (a.N % 256 == 0 && b61 >= 2 * cus) code = 61;
         else if (a.N % 128 == 0 && b62 >= 150) code = 62;
         else code = 42;
-    } else if (ok3 && a.M <= 256 && a.K >= 1024) {
+    } else if (!no_producer && ok3 && a.M <= 256 && a.K >= 1024) {
         code = 69;
-    } else if (ok3 && a.N % 128 == 0 && a.K >= 1024 && b66 * 2 >= cus && b66 <= cus) {
+    } else if (!no_producer && ok3 && a.N % 128 == 0 && a.K >= 1024 && b66 * 2 >= cus && b66 <= cus) {
         code = 66;
     } else if (n160 && a.K >= 2048 && a.N <= 1280 && rounds(blocks(128, 160))) {
         code = 92;
@@ -1295,11 +1304,14 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
         code = 62;
     } else if (a.N >= 2048 && a.K >= 1024 && blocks(128, 128) >= cus) {
         code = ok3 ? 51 : 1;
-    } else if (blocks(128, 64) >= cus * 7 / 2 || a.K >= 4096) {
-        code = ok3 ? 42 : 2;
+    } else if (blocks(128, 64) >= cus * 7 / 2 || a.K >= 4096 || (a.K >= 1024 && blocks(128, 64) >= cus)) {
+        code = ok3 ? 42 : 2;      // last clause: the M 2048 x N 1280 x K 1280 projections, -0.75 % UNet time in tools/tile_trials.py
     } else {
         code = ok3 ? 43 : 13;
     }
+    for (int i = 0; i < g_n_overrides; ++i)
+        if (g_overrides[i].mode == (MODE == 1) && g_overrides[i].M == a.M && g_overrides[i].N == a.N && g_overrides[i].K == a.K)
+            code = g_overrides[i].code;
     if (g_force_tile) code = g_force_tile;
     const int tile = code % 10, ver = code / 10;
     int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
@@ -1448,6 +1460,21 @@ int fie_debug_force_tile(int t) {
     g_force_order = t >= 1000 ? (t / 1000) - 1 : -1;      // 1000 + code: order 0, 2000 + code: order 1
     g_force_tile = t % 1000;
     return FIE_OK;
+}
+
+int fie_debug_tile_override(const char* spec) {
+    g_n_overrides = 0;
+    if (!spec) return FIE_OK;
+    const char* q = spec;
+    while (*q && g_n_overrides < 32) {
+        TileOverride o;
+        int used = 0;
+        if (sscanf(q, "%d,%d,%d,%d=%d%n", &o.mode, &o.M, &o.N, &o.K, &o.code, &used) != 5) break;
+        g_overrides[g_n_overrides++] = o;
+        q += used;
+        if (*q == ';') ++q;
+    }
+    return g_n_overrides;
 }
 
 int fie_debug_extra_lds(int bytes) {

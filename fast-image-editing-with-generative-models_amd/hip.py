@@ -56,6 +56,7 @@ SIGNATURES = {
     "fie_debug_attn_variant": [_I],
     "fie_debug_gn_onepass": [_I],
     "fie_debug_extra_lds": [_I],
+    "fie_debug_tile_override": [_c.c_char_p],
 }
 
 _lib = None

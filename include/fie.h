@@ -169,6 +169,7 @@ int fie_lcm_step_f32(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, floa
  * Process-global; not part of the drop-in surface. */
 int fie_debug_force_tile(int tile);
 int fie_debug_attn_variant(int variant);   /* 0 = default kernel, 1 = first-generation kernel (A/B benchmarking) */
+int fie_debug_tile_override(const char* spec); /* "mode,M,N,K=code;..." per-shape tile codes (whole-pipeline A/B); NULL clears; returns the count */
 int fie_debug_extra_lds(int bytes);        /* pad the v3 GEMM/conv kernels' dynamic LDS (occupancy A/B probe); 0 = off */
 int fie_debug_gn_onepass(int enable);      /* 1 = default (single-pass GroupNorm on small maps), 0 = always partial/finalize/apply */
 
