@@ -1312,9 +1312,12 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     for (int i = 0; i < g_n_overrides; ++i)
         if (g_overrides[i].mode == (MODE == 1) && g_overrides[i].M == a.M && g_overrides[i].N == a.N && g_overrides[i].K == a.K)
             code = g_overrides[i].code;
+    const int override_order = code >= 1000 ? code / 1000 - 1 : -1;     // 1000 + code: order 0, 2000 + code: order 1 (overrides only)
+    code %= 1000;
     if (g_force_tile) code = g_force_tile;
     const int tile = code % 10, ver = code / 10;
     int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
+    if (ver == 4 && tile >= 4) { bm = tile == 4 ? 128 : 64; bn = 64; }               // 44 = 128x64 x 4 stages, 45 / 46 = 64x64 x 4 / 6 stages
     if (ver == 6) {      // 61-63 v3 8-wave tiles, 64 four-phase 256x256, 65-69 producer-wave kernels (gemm6)
         static const int bms[10] = {0, 256, 256, 256, 256, 256, 128, 128, 128, 64}, bns[10] = {0, 256, 128, 320, 256, 128, 128, 64, 128, 64};
         bm = bms[tile]; bn = bns[tile];
@@ -1322,7 +1325,7 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     if (ver == 7) { bm = tile == 1 ? 128 : 256; bn = 128; }
     if (ver == 9) { bm = tile == 2 ? 128 : 64; bn = 160; }                          // 91 = 64x160, 92 = 128x160 (4 waves, 3 stages), 93 = 64x160 x 5 stages
     if (ver == 8) { bm = 256; bn = 128; }                                           // 82 = halo-reuse conv, 16x16 patch x 128 channels                        // 71 = ping-pong 128x128, 72 = ping-pong 256x128   // 61 = 256x256 x2, 62 = 256x128 x3, 63 = 256x320 x2 stages (8 waves)
-    FIE_REQUIRE(ver <= 9 && tile >= 1 && (tile <= 3 || ver == 6) && !((ver == 3 || ver == 5 || ver == 7) && tile == 3) && (ver != 8 || tile == 2),
+    FIE_REQUIRE(ver <= 9 && tile >= 1 && (tile <= 3 || ver == 6 || (ver == 4 && tile <= 6)) && !((ver == 3 || ver == 5 || ver == 7) && tile == 3) && (ver != 8 || tile == 2),
                 "bad tile code %d", code);
     a.nbm = (a.M + bm - 1) / bm;
     a.nbn = (a.N + bn - 1) / bn;
@@ -1333,7 +1336,7 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
         const double row_major = abytes + (wbytes <= l2 ? 8 * wbytes : a.nbm * wbytes);
         const double col_major = wbytes + (abytes <= l2 ? 8 * abytes : (wbytes / 8 <= l2 ? 8 * abytes : a.nbn * abytes));
         (void)row_major; (void)col_major;   // measured (profiles/r01_microbench.md): the estimate does not pay; rows-per-XCD stays the default
-        a.order = g_force_order >= 0 ? g_force_order : 0;
+        a.order = g_force_order >= 0 ? g_force_order : (override_order >= 0 ? override_order : 0);
     }
     const dim3 grid((unsigned)(a.nbm * a.nbn)), block(256);
     if (ver == 8) {
@@ -1369,7 +1372,10 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
             } else if (ver == 4) {
                 if (tile == 1) launch3_t<128, 128, 3, M3>(ctx, a, grid);
                 else if (tile == 2) launch3_t<128, 64, 3, M3>(ctx, a, grid);
-                else launch3_t<64, 64, 3, M3>(ctx, a, grid);
+                else if (tile == 3) launch3_t<64, 64, 3, M3>(ctx, a, grid);
+                else if (tile == 4) launch3_t<128, 64, 4, M3>(ctx, a, grid);
+                else if (tile == 5) launch3_t<64, 64, 4, M3>(ctx, a, grid);
+                else launch3_t<64, 64, 6, M3>(ctx, a, grid);
             } else {
                 if (tile == 1) launch3_t<128, 128, 3, M3, 8>(ctx, a, grid);
                 else launch3_t<128, 64, 3, M3, 8>(ctx, a, grid);
