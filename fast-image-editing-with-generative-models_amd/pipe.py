@@ -38,7 +38,7 @@ class HipImg2ImgPipeline:
         self.last_stats = {}
         self.timing = None         # set to [] to collect per-stage HIP-event timings in run_device()
         self.use_graph = os.environ.get("FIE_NO_GRAPH", "0") != "1"
-        self._graphs = {}
+        self._graphs = {}          # never pruned: destroying a graph and capturing another gave a slow graph (121 vs 81 ms)
         self._side = None
         self._slot_streams = {}
         self._host_out = {}
