@@ -236,9 +236,7 @@ def main():
         torch.cuda.synchronize()
 
     nfl = 1 if args.no_graph else max(1, args.in_flight)
-    # ROCm keeps separate hardware queues per stream priority, so alternating priorities guarantees that two edits in
-    # flight never share one queue (same-priority streams are hashed onto 4 queues and may collide: measured 11.1 vs 13.8)
-    streams = [torch.cuda.Stream(priority=-(i % 2)) for i in range(nfl)]
+    streams = [pipe.new_slot_stream(i, equal_priority=True) for i in range(nfl)]
 
     def run(job, s):
         if args.no_graph:

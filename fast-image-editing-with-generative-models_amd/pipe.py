@@ -281,13 +281,20 @@ class HipImg2ImgPipeline:
             out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
         return out
 
+    def new_slot_stream(self, slot, equal_priority=False):
+        """A stream for graph slot `slot`.  Odd slots take a high-priority stream: ROCm keeps separate hardware queues per
+        priority, so slots 0 and 1 can never be dealt onto one queue (which would serialise the two edits), and with worker
+        threads (PIL in -> PIL out) the priority split measures best: 13.3 vs 12.9 images/s.  `equal_priority` is for a caller
+        that replays device-resident jobs back to back (bench.py's timed loop: 14.1 vs 13.8 images/s) and needs >= 8 hardware
+        queues (fie_amd.py sets 16) for the streams to stay on separate queues."""
+        few_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8
+        return torch.cuda.Stream(device=self.ctx.device, priority=0 if equal_priority and not few_queues else -(slot % 2))
+
     def slot_stream(self, slot):
         """Stream of graph slot `slot`.  Every slot, slot 0 included, owns a stream: replaying an edit's graph on the legacy
-        null stream costs +30 ms per edit once other streams exist in the process (measured, 92 vs 122 ms end to end).
-        Odd slots are high-priority: ROCm gives each priority its own hardware queues, so slots 0 and 1 can never be hashed
-        onto one queue (which would serialise the two edits)."""
+        null stream costs +30 ms per edit once other streams exist in the process (measured, 92 vs 122 ms end to end)."""
         if slot not in self._slot_streams:
-            self._slot_streams[slot] = torch.cuda.Stream(device=self.ctx.device, priority=-(slot % 2))
+            self._slot_streams[slot] = self.new_slot_stream(slot)
         return self._slot_streams[slot]
 
     def __call__(self, prompt, negative_prompt="", image=None, control_image=None, strength=0.8,
