@@ -52,6 +52,7 @@ SIGNATURES = {
     "fie_lcm_step_f32": [_P, _P, _L, _I, _F, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _I, _F, _P],
     "fie_canny_workspace_bytes": [_I, _I],
     "fie_canny_rgb_device_u8": [_P, _P, _I, _I, _I, _I, _P, _P, _c.POINTER(_I)],
+    "fie_resize_rgb_u8": [_P, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P],
     "fie_debug_force_tile": [_I],
     "fie_debug_attn_variant": [_I],
     "fie_debug_gn_onepass": [_I],
@@ -117,6 +118,7 @@ class Context:
         self.h = h
         self._stream = None
         self._gn_ws = {}
+        self._resize_tables = {}       # (in, out) -> (taps, bounds, ksize) of the LANCZOS resample, on the device
         self.ws_tag = 0
 
     def sync_stream(self):
@@ -284,6 +286,25 @@ class Context:
         _, h, w, ld = x_nhwc.shape
         out = torch.empty((h, w, 3), device=x_nhwc.device, dtype=torch.uint8)
         _chk((lib().fie_pixels_out_f32_u8 if self.f32 else lib().fie_pixels_out_f16_u8)(self.h, _p(x_nhwc), ld, h, w, _p(out)))
+        return out
+
+    def resize_lanczos(self, rgb_u8, out_h, out_w):
+        """u8 [H, W, 3] device tensor -> u8 [out_h, out_w, 3], bit-exact with PIL's `resize(..., Image.LANCZOS)`."""
+        from . import resize
+        self.sync_stream()
+        h, w, _ = rgb_u8.shape
+        assert rgb_u8.dtype == torch.uint8 and rgb_u8.is_contiguous()
+        tabs = []
+        for n_in, n_out in ((w, out_w), (h, out_h)):
+            key = (n_in, n_out)
+            if n_in != n_out and key not in self._resize_tables:
+                kk, bounds, ks = resize.coefficients(n_in, n_out)
+                self._resize_tables[key] = (torch.from_numpy(kk).to(self.device), torch.from_numpy(bounds).to(self.device), ks)
+            tabs.append(self._resize_tables.get(key) if n_in != n_out else (None, None, 0))
+        out = torch.empty((out_h, out_w, 3), device=rgb_u8.device, dtype=torch.uint8)
+        tmp = torch.empty((h, out_w, 3), device=rgb_u8.device, dtype=torch.uint8) if (h != out_h and w != out_w) else None
+        (kx, bx, ksx), (ky, by, ksy) = tabs
+        _chk(lib().fie_resize_rgb_u8(self.h, _p(rgb_u8), h, w, _p(out), out_h, out_w, _p(kx), _p(bx), ksx, _p(ky), _p(by), ksy, _p(tmp)))
         return out
 
     def canny_device(self, rgb_u8, low=100, high=200):

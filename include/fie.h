@@ -185,6 +185,15 @@ int64_t fie_canny_workspace_bytes(int H, int W);
 int fie_canny_rgb_device_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int low, int high, void* workspace,
                             uint8_t* edges_rgb, int* iterations);
 
+/* ---- K13 LANCZOS resize on the device, bit-exact with Pillow's 8-bit resample.  Replaces
+ * `image.resize((1024, 1024), Image.LANCZOS)` at src/pipeline.py:251 (the PIL image is uploaded at its own size instead).
+ *   src u8 [H, W, 3] -> dst u8 [OH, OW, 3] on the device; kx/ky: int32 [OW|OH, ks] 22-bit fixed-point taps, bx/by: int32
+ *   [OW|OH, 2] = (first input index, tap count) -- Pillow's precompute_coeffs / normalize_coeffs_8bpc, restated in
+ *   fie_amd/resize.py; a table may be NULL when that axis keeps its size.  tmp: u8 [H, OW, 3] scratch (both axes change).
+ *   Asynchronous on the ctx stream. */
+int fie_resize_rgb_u8(fie_ctx* ctx, const uint8_t* src, int H, int W, uint8_t* dst, int OH, int OW, const int* kx,
+                      const int* bx, int ksx, const int* ky, const int* by, int ksy, uint8_t* tmp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,13 +101,18 @@ class FastEditor:
                                   else "disabled (faster, needs more VRAM)"))
         log("Initialization complete!")
 
-    def _canny_device(self, image, low_threshold, high_threshold):
+    def _canny_device(self, image, low_threshold, high_threshold, size=None):
         """PIL -> (u8 HWC source on the device, u8 HWC edge map on the device): gray, Sobel, NMS and hysteresis run in HIP
-        kernels (csrc/canny_device.hip), integer exact."""
+        kernels (csrc/canny_device.hip), integer exact.  `size` = (width, height): LANCZOS-resize first, as
+        `image.resize(size, Image.LANCZOS)` does -- on the device for RGB images, through PIL for any other mode."""
+        if size is not None and image.size != tuple(size) and image.mode != "RGB":
+            image = image.resize(size, Image.LANCZOS)
         arr = np.array(image)
         if arr.ndim == 2:
             arr = np.stack([arr] * 3, axis=2)
         src = torch.from_numpy(np.ascontiguousarray(arr[..., :3])).to(self.pipe.ctx.device)
+        if size is not None and (src.shape[1], src.shape[0]) != tuple(size):
+            src = self.pipe.ctx.resize_lanczos(src, size[1], size[0])
         return src, self.pipe.ctx.canny_device(src, low_threshold, high_threshold)
 
     def preprocess_image(self, image, low_threshold=100, high_threshold=200):
@@ -120,12 +125,12 @@ class FastEditor:
         generator = None
         if seed is not None:
             generator = torch.Generator(device=self.device).manual_seed(seed)
-        input_image = image.resize((1024, 1024), Image.LANCZOS)
-        # same data flow as the reference (:251-272) with the two images kept in HBM: preprocess_image()'s PIL round trip
-        # (D2H of the edge map + H2D again inside the pipeline) is skipped
+        # same data flow as the reference (:251-272) with the images kept in HBM: the LANCZOS resize to 1024x1024 (:251) runs
+        # on the device (bit-exact with Pillow, csrc/resize.hip) on the uploaded original, and preprocess_image()'s PIL round
+        # trip (D2H of the edge map + H2D again inside the pipeline) is skipped
         slot = getattr(self._tls, "slot", 0)
         with self.pipe.eager_lock, torch.cuda.stream(self.pipe.slot_stream(slot)):
-            source_dev, control_dev = self._canny_device(input_image, canny_low_threshold, canny_high_threshold)
+            source_dev, control_dev = self._canny_device(image, canny_low_threshold, canny_high_threshold, size=(1024, 1024))
         return self.pipe(slot=slot, prompt=prompt, negative_prompt=negative_prompt, image=source_dev,
                          control_image=control_dev, strength=strength, num_inference_steps=num_inference_steps,
                          guidance_scale=guidance_scale, controlnet_conditioning_scale=controlnet_conditioning_scale,
@@ -145,7 +150,7 @@ class FastEditor:
         srcs, ctls = [], []
         with self.pipe.eager_lock, torch.cuda.stream(self.pipe.slot_stream(slot)):
             for im in images:
-                s_dev, c_dev = self._canny_device(im.resize((1024, 1024), Image.LANCZOS), canny_low_threshold, canny_high_threshold)
+                s_dev, c_dev = self._canny_device(im, canny_low_threshold, canny_high_threshold, size=(1024, 1024))
                 srcs.append(s_dev)
                 ctls.append(c_dev)
         return self.pipe(slot=slot, prompt=list(prompts), negative_prompt=negative_prompts, image=srcs, control_image=ctls,

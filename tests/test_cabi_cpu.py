@@ -155,3 +155,16 @@ def test_evaluate_schema_matches_reference_results(tmp_path):
     assert set(s["overall"]["ssim"]) == {"mean", "std", "median"} and 0 < s["overall"]["ssim"]["mean"] < 1
     assert set(s["by_category"]) == {"0", "1"} and s["by_category"]["0"]["count"] == 3
     assert set(s["by_category"]["0"]["psnr"]) == {"mean", "std"} and s["overall"]["lpips"]["mean"] is None
+
+
+@pytest.mark.parametrize("h,w,oh,ow", [(512, 512, 1024, 1024), (333, 517, 1024, 1024), (1500, 1100, 1024, 1024), (64, 48, 96, 80), (1024, 700, 1024, 1024)])
+def test_lanczos_tables_match_pillow(h, w, oh, ow):
+    """The restated coefficient / bounds tables of Pillow's 8-bit LANCZOS resample (host side of csrc/resize.hip) reproduce
+    `Image.resize(..., Image.LANCZOS)` bit for bit (the two passes emulated in numpy)."""
+    from PIL import Image
+    from fie_amd import resize
+    rng = np.random.default_rng(h * 7 + w)
+    a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    a[: h // 2] = (np.linspace(0, 255, w)[None, :, None] * np.ones((h // 2, 1, 3))).astype(np.uint8)      # smooth half + noise half
+    ref = np.asarray(Image.fromarray(a).resize((ow, oh), Image.LANCZOS))
+    assert np.array_equal(resize.resample_numpy(a, oh, ow), ref)

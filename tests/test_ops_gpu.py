@@ -303,3 +303,15 @@ def test_canny_device_long_chain(fie):
     got = fie.canny_device(torch.from_numpy(img).to(DEV), 100, 200).cpu().numpy()
     ref = ocanny.canny_rgb(img, 100, 200)
     assert np.array_equal(got, ref) and ref[:, 900:].max() == 255 and fie.canny_passes > 8
+
+
+@pytest.mark.parametrize("h,w,oh,ow", [(512, 512, 1024, 1024), (333, 517, 1024, 1024), (1500, 1100, 1024, 1024), (64, 48, 96, 80),
+                                       (1024, 700, 1024, 1024), (700, 1024, 1024, 1024), (1024, 1024, 1024, 1024)])
+def test_resize_lanczos_device_bit_exact_with_pillow(fie, h, w, oh, ow):
+    from PIL import Image
+    rng = np.random.default_rng(h * 7 + w)
+    a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    a[: h // 2] = (np.linspace(0, 255, w)[None, :, None] * np.ones((h // 2, 1, 3))).astype(np.uint8)
+    ref = np.asarray(Image.fromarray(a).resize((ow, oh), Image.LANCZOS))
+    out = fie.resize_lanczos(torch.from_numpy(a).to(DEV), oh, ow).cpu().numpy()
+    assert np.array_equal(out, ref)
