@@ -186,7 +186,7 @@ class HipImg2ImgPipeline:
         conds = []
         for i in range(n):
             x_img = ctx.pixels_in(imgs[i], True)
-            conds.append(ctx.pixels_in(ctls[i], False, copies=nb))
+            conds.append(ctx.pixels_in(ctls[i], False))
             moments, _ = self.vae.encode_moments(x_img)
             ctx.latent_prep(moments, job["noises"][i * per], job["noises"][i * per + 1], hw, sf, steps[0]["sqrt_ab"],
                             steps[0]["sqrt_1mab"], latents[i], model_in[i * nb:(i + 1) * nb])
@@ -197,7 +197,11 @@ class HipImg2ImgPipeline:
         # 6. per-image invariants
         self.unet.begin_image(pooled, job["time_ids"])
         self.controlnet.begin_image(pooled, job["time_ids"])
+        # the edge-map embedding is the same for the CFG rows of an image: computed once per image, then repeated (upstream runs
+        # it on the duplicated batch; the values are identical)
         cond_emb = self.controlnet.cond_embedding(cond)
+        if nb > 1:
+            cond_emb = cond_emb.repeat_interleave(nb, dim=0)
         decode_in = torch.empty((n, lh, lw, 8), device=dev, dtype=ctx.dtype)
         self._mark("cond_embed")
         # 7. denoising loop
