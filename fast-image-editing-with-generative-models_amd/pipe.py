@@ -41,6 +41,8 @@ class HipImg2ImgPipeline:
         self._graphs = {}          # never pruned: destroying a graph and capturing another gave a slow graph (121 vs 81 ms)
         self._side = None
         self._slot_streams = {}
+        self._n_forked = 0
+        self._fork_override = None
         self._host_out = {}
         self.eager_lock = threading.RLock()
         self.fork_streams = os.environ.get("FIE_NO_FORK", "0") != "1"
@@ -143,7 +145,7 @@ class HipImg2ImgPipeline:
         ControlNet trunk).  `fork_streams = False` keeps the whole edit on one stream.  Overlap between the branches
         (and between edits in flight) needs the streams to land on different hardware queues: see GPU_MAX_HW_QUEUES in
         fie_amd.py."""
-        if not self.fork_streams:
+        if not (self.fork_streams if self._fork_override is None else self._fork_override):
             return torch.cuda.current_stream(self.ctx.device)
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.ctx.device)
@@ -235,6 +237,8 @@ class HipImg2ImgPipeline:
         self._latents = latents
         return out_u8
 
+    MAX_FORKED_GRAPHS = 6
+
     _TENSOR_KEYS = ("ids_l", "ids_g", "eos_rows", "img_u8", "ctl_u8", "time_ids")
 
     def run_device_graphed(self, job, slot=0):
@@ -243,12 +247,23 @@ class HipImg2ImgPipeline:
         The returned u8 image is the graph's static output buffer (consume it before the next replay).
         `slot` selects an independent graph instance (own static buffers / scratch) so that several edits can be in
         flight on different streams of one GPU."""
-        key = (job["hw"], job["nb"], tuple(st["t"] for st in job["steps"]), job["guidance"], job["cn_scale"], slot, self.fork_streams,
-               job.get("n", 1))
+        base = (job["hw"], job["nb"], tuple(st["t"] for st in job["steps"]), job["guidance"], job["cn_scale"], slot, job.get("n", 1))
+        # A forked graph owns extra runtime streams; past ~8 such graphs in one process new ones start sharing hardware queues
+        # with their own launch stream and replay 50 % slower (measured: 82 -> 125 ms, tools/edit_ab.py).  Beyond the budget a
+        # new key is captured on one stream instead (87 ms): slower than a healthy forked graph, never pathological.
+        fork = self.fork_streams and ((base, True) in self._graphs or self._n_forked < self.MAX_FORKED_GRAPHS)
+        key = (base, fork)
         entry = self._graphs.get(key)
         if entry is None:
             with self.eager_lock:                       # eager launches + capture go through the one C-ABI context
-                entry = self._graphs.get(key) or self._capture(key, job, slot)
+                entry = self._graphs.get(key)
+                if entry is None:
+                    self._fork_override = fork           # read by _side_stream() during this capture only
+                    try:
+                        entry = self._capture(key, job, slot)
+                    finally:
+                        self._fork_override = None
+                    self._n_forked += int(fork)
         graph, static, out = entry
         if static is not job:
             for k in self._TENSOR_KEYS:

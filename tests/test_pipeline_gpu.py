@@ -270,3 +270,24 @@ def test_run_batch_in_flight_and_batched_match_serial(fie, tmp_path):
     for i in range(5):
         assert np.array_equal(outs["threads"][i], outs["serial"][i])
         assert np.abs(outs["batched"][i] - outs["serial"][i]).max() <= 2
+
+
+def test_forked_graph_budget(rig):
+    """Keys beyond MAX_FORKED_GRAPHS are captured on one stream (same results): many forked graphs in one process end up
+    sharing hardware queues and replay 50 % slower."""
+    cfgs, sds32, pipe = rig
+    img = synth_image(21, 128)
+    ctrl = Image.fromarray(np.zeros((128, 128, 3), np.uint8))
+    old = pipe.MAX_FORKED_GRAPHS, pipe._n_forked, pipe.use_graph
+    try:
+        pipe.use_graph = True
+        pipe.MAX_FORKED_GRAPHS = pipe._n_forked + 1
+        outs = []
+        for g in (1.31, 1.32):           # two new keys: the first is captured forked, the second on one stream
+            outs.append(np.asarray(pipe(prompt="a [toy]", image=img, control_image=ctrl, strength=0.5, guidance_scale=g,
+                                        generator=torch.Generator("cpu").manual_seed(1)).images[0]))
+        forks = sorted(k[1] for k in pipe._graphs if k[0][3] in (1.31, 1.32))
+        assert forks == [False, True]
+        assert np.abs(outs[0].astype(int) - outs[1].astype(int)).max() <= 8          # guidance differs by 0.01 only
+    finally:
+        pipe.MAX_FORKED_GRAPHS, pipe.use_graph = old[0], old[2]

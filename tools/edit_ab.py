@@ -14,11 +14,11 @@ from src.pipeline import FastEditor  # noqa: E402
 specs = sys.argv[1:] or [""]
 ed = FastEditor(model_name="ssd-1b", use_full_controlnet=True, enable_cpu_offload=False)
 pipe = ed.pipe
+pipe.fork_streams = False      # single-stream graphs: immune to the hardware-queue collisions that many forked graphs in one process cause
 img = synth_item_image(3).resize((1024, 1024))
 ctrl = ed.preprocess_image(img)
-# one graph per (round, spec): a captured graph keeps the kernels chosen at capture time.  Graphs are never destroyed here --
-# destroying one and capturing another was measured to give a slow graph (121 vs 81 ms: the new graph's branch stream lands
-# on a busy hardware queue) -- so every capture gets its own key through a slightly different guidance value.
+# one graph per (round, spec): a captured graph keeps the kernels chosen at capture time; every capture gets its own key
+# through a slightly different guidance value (graphs are never destroyed).
 n_cap = 0
 for rnd in range(3):
     for sp in specs:
