@@ -471,7 +471,7 @@ int launch_attn2(fie_ctx* ctx, const AttnArgs& a, int B) {
     return FIE_OK;
 }
 
-int g_attn_variant = 0;   // tuning hook: 0 = v2 (LDS-DMA ring, deferred rescale), 1 = v1
+int g_attn_variant = 0;   // tuning hook: 0 = v2 (LDS-DMA ring, deferred rescale), 1 = v1, 2 / 3 = v2 with 128 / 64 queries per block forced
 
 }  // namespace
 
@@ -495,6 +495,8 @@ extern "C" int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const
         return launch_attn<64, 1, 64>(ctx, a, B);
     }
     if (D == 512) return launch_attn2<512, 1, 32>(ctx, a, B);
+    if (g_attn_variant == 2) return launch_attn2<64, 2, 64>(ctx, a, B);      // A/B: 128 queries per block everywhere
+    if (g_attn_variant == 3) return launch_attn2<64, 1, 64>(ctx, a, B);      // A/B: 64 queries per block everywhere
     if (blocks128 >= ctx->num_cus * 2) return launch_attn2<64, 2, 64>(ctx, a, B);
     return launch_attn2<64, 1, 64>(ctx, a, B);
 }
