@@ -282,6 +282,8 @@ bool gn_onepass(fie_ctx* ctx, const GnArgsT<T>& p, int B) {
     const dim3 grid((unsigned)p.G, (unsigned)B);
     if (V == 8 && nv <= 5) hipLaunchKernelGGL((gn_onepass_kernel<8, 5, T>), grid, dim3(GN1_THREADS), 0, ctx->stream, p);
     else if (V == 8 && nv <= 10) hipLaunchKernelGGL((gn_onepass_kernel<8, 10, T>), grid, dim3(GN1_THREADS), 0, ctx->stream, p);
+    // V = 4 at rows = 4096 (64x64 latents, 21 vectors) measured SLOWER than the three-kernel path (28.5 vs 22.0 us: 40-byte
+    // slices at a 1280-byte stride), so the bound stays at 20
     else if (V == 4 && nv <= 20) hipLaunchKernelGGL((gn_onepass_kernel<4, 20, T>), grid, dim3(GN1_THREADS), 0, ctx->stream, p);
     else return false;
     return true;

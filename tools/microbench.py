@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-shape kernel micro-benchmark on the GPU box (HIP-event timed, random data): TFLOP/s of the GEMM / conv /
-attention shapes that make up the SSD-1B + ControlNet + VAE hot path.  usage: tools/microbench.py [gemm|conv|attn|all] [tiles]"""
+attention shapes that make up the SSD-1B + ControlNet + VAE hot path, GB/s of the HBM-bound norm / element-wise kernels.
+usage: tools/microbench.py [gemm|conv|attn|norm|all] [tiles]"""
 import os
 import sys
 
@@ -93,7 +94,42 @@ def run(which, tiles):
             print(f"attn B={b} H={hn} Tq={tq} Tk={tk} D={d}: " + "  ".join(res), flush=True)
 
 
+def run_norm():
+    """HBM-bound kernels: algorithmic bytes (reads + writes of the tensor) / time against the ~8 TB/s HBM3E peak."""
+    for b, rows, c, note in [(1, 1048576, 128, "VAE 1024^2"), (1, 262144, 256, "VAE 512^2"), (1, 65536, 512, "VAE 256^2"),
+                             (2, 16384, 320, "UNet 128^2"), (2, 4096, 640, "UNet 64^2"), (2, 1024, 1280, "UNet 32^2 (single pass)")]:
+        x = torch.randn(b, rows, c, device=DEV, dtype=torch.float16)
+        g, bt = torch.randn(c, device=DEV, dtype=torch.float16), torch.randn(c, device=DEV, dtype=torch.float16)
+        out = torch.empty_like(x)
+        cg = c // 32
+        v = 8 if cg % 8 == 0 else (4 if cg % 4 == 0 else 0)
+        nv = -(-rows // (1024 // (cg // v))) if v else 0
+        single = (v == 8 and nv <= 10) or (v == 4 and nv <= 20)          # csrc/norm.hip gn_onepass()
+        for onepass in ((1, 0) if single else (0,)):
+            hip.lib().fie_debug_gn_onepass(onepass)
+            dt = timeit(lambda: ctx.groupnorm(x, g, bt, 32, 1e-5, True, out=out))
+            passes = 2 if onepass else 3
+            print(f"groupnorm+SiLU {note:24s} B={b} rows={rows:8d} C={c:5d} {'single-pass' if onepass else '3-kernel   '}: {dt * 1e6:7.1f} us "
+                  f"{passes * x.numel() * 2 / dt / 1e9:7.0f} GB/s ({passes} passes over the tensor)", flush=True)
+        hip.lib().fie_debug_gn_onepass(1)
+    for rows, c in [(2048, 1280), (8192, 640), (154, 1280)]:
+        x = torch.randn(rows, c, device=DEV, dtype=torch.float16)
+        g, bt = torch.randn(c, device=DEV, dtype=torch.float16), torch.randn(c, device=DEV, dtype=torch.float16)
+        out = torch.empty_like(x)
+        dt = timeit(lambda: ctx.layernorm(x, g, bt, out=out))
+        print(f"layernorm rows={rows:6d} C={c:5d}: {dt * 1e6:7.1f} us {2 * x.numel() * 2 / dt / 1e9:7.0f} GB/s", flush=True)
+    img = torch.randint(0, 256, (1024, 1024, 3), device=DEV, dtype=torch.uint8)
+    dt = timeit(lambda: ctx.pixels_in(img, True))
+    print(f"pixels_in 1024^2: {dt * 1e6:7.1f} us {(img.numel() + 1024 * 1024 * 8 * 2) / dt / 1e9:7.0f} GB/s", flush=True)
+    small = torch.randint(0, 256, (512, 512, 3), device=DEV, dtype=torch.uint8)
+    dt = timeit(lambda: ctx.resize_lanczos(small, 1024, 1024))
+    print(f"LANCZOS 512^2 -> 1024^2 (two passes): {dt * 1e6:7.1f} us", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3]
-    run(which, tiles)
+    if which in ("norm", "all"):
+        run_norm()
+    if which != "norm":
+        run(which, tiles)
