@@ -1,0 +1,102 @@
+"""Host logic of run_batch.py without a GPU: the per-image loop, --batch_size grouping, --in_flight worker threads, per-image
+failure isolation (reference run_batch.py:176-261) -- driven through a stub editor."""
+import threading
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import run_batch
+
+
+class StubEditor:
+    """Implements the slice of FastEditor that run_batch touches; records how it was called."""
+
+    def __init__(self, fail_on=()):
+        self.calls, self.batches, self.slots, self.fail_on = [], [], set(), set(fail_on)
+        self.in_flight = 1
+        self._tls = threading.local()
+        self._lock = threading.Lock()
+
+    def _out(self, prompt):
+        if prompt in self.fail_on:
+            raise RuntimeError(f"boom on {prompt}")
+        return Image.fromarray(np.full((8, 8, 3), len(prompt) % 251, dtype=np.uint8))
+
+    def edit(self, image, prompt, **kw):
+        with self._lock:
+            self.calls.append(prompt)
+            self.slots.add(getattr(self._tls, "slot", 0))
+        return self._out(prompt)
+
+    def edit_batch(self, images, prompts, **kw):
+        with self._lock:
+            self.batches.append(list(prompts))
+        return [self._out(p) for p in prompts]
+
+    def set_in_flight(self, n):
+        self.in_flight = n
+
+    def worker_slot(self, slot):
+        self._tls.slot = slot
+
+    def clear_memory(self):
+        pass
+
+
+@pytest.fixture
+def dataset(tmp_path):
+    src = tmp_path / "src"
+    entries = []
+    for i in range(7):
+        rel = f"{i % 3}_cat/{i:012d}.png"
+        (src / f"{i % 3}_cat").mkdir(parents=True, exist_ok=True)
+        Image.fromarray(np.full((16, 16, 3), i, dtype=np.uint8)).save(src / rel)
+        entries.append((i, f"{i:012d}", {"image_path": rel, "editing_prompt": f"prompt {'x' * i}", "editing_type_id": str(i % 3)}))
+    entries.append((7, "nosrc", {"image_path": "0_cat/missing.png", "editing_prompt": "y", "editing_type_id": "0"}))
+    entries.append((8, "noprompt", {"image_path": "0_cat/000000000000.png", "editing_prompt": "", "editing_type_id": "0"}))
+    entries.append((9, "evil", {"image_path": "../../etc/passwd", "editing_prompt": "z", "editing_type_id": "0"}))
+    return src, entries
+
+
+def _args(src, out, *extra):
+    return run_batch.build_parser().parse_args(["--source_dir", str(src), "--output_dir", str(out), "--seed", "42"] + list(extra))
+
+
+def test_serial_loop_counts_and_outputs(dataset, tmp_path):
+    src, entries = dataset
+    ed = StubEditor()
+    r = run_batch.process_shard(ed, entries, _args(src, tmp_path / "o"), str(tmp_path / "o" / "e"), str(tmp_path / "o" / "c"))
+    assert (r["processed"], r["skipped"], r["failed"]) == (7, 0, 3)
+    assert [row["index"] for row in r["rows"]] == list(range(7)) and len(ed.calls) == 7 and not ed.batches
+    assert all((tmp_path / "o" / "e" / e["image_path"]).exists() for _, _, e in entries[:7])
+    r2 = run_batch.process_shard(ed, entries, _args(src, tmp_path / "o", "--skip_existing"), str(tmp_path / "o" / "e"), str(tmp_path / "o" / "c"))
+    assert (r2["processed"], r2["skipped"], r2["failed"]) == (0, 8, 2)       # "noprompt" now finds image 0's output: skipped
+
+
+def test_batched_loop_groups_and_flushes_the_tail(dataset, tmp_path):
+    src, entries = dataset
+    ed = StubEditor()
+    r = run_batch.process_shard(ed, entries, _args(src, tmp_path / "o", "--batch_size", "3"), str(tmp_path / "o" / "e"), str(tmp_path / "o" / "c"))
+    assert (r["processed"], r["failed"]) == (7, 3) and not ed.calls
+    assert [len(b) for b in ed.batches] == [3, 3, 1]
+    assert [row["index"] for row in r["rows"]] == list(range(7))
+
+
+def test_failure_is_isolated_per_image_or_per_batch(dataset, tmp_path):
+    src, entries = dataset
+    bad = entries[4][2]["editing_prompt"]
+    r = run_batch.process_shard(StubEditor(fail_on=[bad]), entries, _args(src, tmp_path / "a"), str(tmp_path / "a" / "e"), str(tmp_path / "a" / "c"))
+    assert (r["processed"], r["failed"]) == (6, 4)
+    r = run_batch.process_shard(StubEditor(fail_on=[bad]), entries, _args(src, tmp_path / "b", "--batch_size", "3"),
+                                str(tmp_path / "b" / "e"), str(tmp_path / "b" / "c"))
+    assert (r["processed"], r["failed"]) == (4, 6)                           # the failing batch (images 3-5) fails as a whole
+
+
+def test_in_flight_workers_cover_every_entry_once(dataset, tmp_path):
+    src, entries = dataset
+    ed = StubEditor()
+    r = run_batch.process_shard(ed, entries, _args(src, tmp_path / "o", "--in_flight", "2"), str(tmp_path / "o" / "e"), str(tmp_path / "o" / "c"))
+    assert ed.in_flight == 2 and ed.slots == {0, 1}
+    assert (r["processed"], r["failed"]) == (7, 3) and sorted(ed.calls) == sorted(e["editing_prompt"] for _, _, e in entries[:7])
+    assert [row["index"] for row in r["rows"]] == list(range(7))
