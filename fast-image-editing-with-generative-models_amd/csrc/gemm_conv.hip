@@ -1315,6 +1315,29 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     const int override_order = code >= 1000 ? code / 1000 - 1 : -1;     // 1000 + code: order 0, 2000 + code: order 1 (overrides only)
     code %= 1000;
     if (g_force_tile) code = g_force_tile;
+    if (code == 70) {
+        // column split for GEMMs whose 256x256 grid is a little more than one round (FF1: 8 x 40 tiles on 256 CUs): the first
+        // floor(CUs / row tiles) column tiles run as exactly one round of 256x256 tiles, the remaining columns as 256x128 tiles
+        const int nbm256 = (a.M + 255) / 256;
+        const int n1 = (int)(cus / nbm256) * 256;
+        FIE_REQUIRE(MODE == 0 && ok3 && n1 > 0 && n1 < a.N && a.N % 256 == 0, "tile code 70: shape not eligible for the column split");
+        const int save_force = g_force_tile;
+        GemmArgs p1 = a, p2 = a;
+        p1.N = n1;
+        p2.N = a.N - n1;
+        p2.Wt = a.Wt + (int64_t)n1 * a.ldw;
+        p2.w_bytes = a.w_bytes - (int64_t)n1 * a.ldw * 2;
+        if (a.bias) p2.bias = a.bias + n1;
+        if (a.rowbias) p2.rowbias = a.rowbias + n1;
+        if (a.res) p2.res = a.res + n1;
+        p2.C = a.C + (a.act == FIE_ACT_GEGLU ? n1 / 2 : n1);
+        g_force_tile = 61;
+        int rc = launch<MODE>(ctx, p1);
+        g_force_tile = 62;
+        if (rc == FIE_OK) rc = launch<MODE>(ctx, p2);
+        g_force_tile = save_force;
+        return rc;
+    }
     const int tile = code % 10, ver = code / 10;
     int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
     if (ver == 4 && tile >= 4) { bm = tile == 4 ? 128 : 64; bn = 64; }               // 44 = 128x64 x 4 stages, 45 / 46 = 64x64 x 4 / 6 stages

@@ -315,3 +315,24 @@ def test_resize_lanczos_device_bit_exact_with_pillow(fie, h, w, oh, ow):
     ref = np.asarray(Image.fromarray(a).resize((ow, oh), Image.LANCZOS))
     out = fie.resize_lanczos(torch.from_numpy(a).to(DEV), oh, ow).cpu().numpy()
     assert np.array_equal(out, ref)
+
+
+def test_tile_override_and_column_split(fie):
+    """`fie_debug_tile_override` steers ONE shape (the whole-UNet trial tools rely on it); code 70 = column split (one full
+    round of 256x256 tiles + the rest as 256x128) with bias / GEGLU epilogue offsets carried across the split."""
+    from fie_amd import hip
+    m, n, k = 4096, 5120, 128
+    a, w, bias = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5), rnd(n, seed=3)
+    ad, bd = a.to(DEV), bias.to(DEV)
+    wp, wg = fie.pack_linear(w.to(DEV)), fie.pack_linear(w.to(DEV), geglu=True)
+    ref = fie.gemm(ad, wp, n, bias=bd)
+    ref_g = fie.gemm(ad, wg, n, bias=bd, act=hip.ACT_GEGLU)
+    try:
+        assert hip.lib().fie_debug_tile_override(f"0,{m},{n},{k}=70;1,1,1,1=42".encode()) == 2
+        out = fie.gemm(ad, wp, n, bias=bd)
+        out_g = fie.gemm(ad, wg, n, bias=bd, act=hip.ACT_GEGLU)
+        other = fie.gemm(ad[:256], wp, n, bias=bd)            # a different M: not overridden
+    finally:
+        assert hip.lib().fie_debug_tile_override(None) == 0
+    assert torch.equal(out, ref) and torch.equal(out_g, ref_g) and torch.equal(other, ref[:256])
+    assert rel_err(ref, a.float() @ w.float().T + bias.float()) < 3e-3

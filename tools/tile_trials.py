@@ -13,17 +13,16 @@ from fie_amd import hip  # noqa: E402
 from src.pipeline import FastEditor  # noqa: E402
 
 TRIALS = {
-    "FF1   0,2048,10240,1280": [2062, 51, 65],
-    "FF2   0,2048,1280,5120": [44, 2042, 2044],
-    "proj  0,2048,1280,1280": [44, 43, 45, 46, 2042],
-    "QKV   0,2048,3840,1280": [2062, 42, 44],
-    "c32   1,2048,1280,11520": [44, 2042, 43, 45],
-    "FF1h  0,8192,5120,640": [2062, 44],
-    "projh 0,8192,640,640": [45, 46, 44, 2043],
-    "FF2h  0,8192,640,2560": [2062, 44],
-    "c64   1,8192,640,5760": [2062, 44],
-    "c128  1,32768,320,2880": [44, 2042],
-    "kv    0,154,2560,2048": [45, 46, 69],
+    "FF1   0,2048,10240,1280": [42, 51, 65, 61, 70],
+    "FF2   0,2048,1280,5120": [66, 43, 51, 62, 44],
+    "proj  0,2048,1280,1280": [43, 66, 91, 62, 44],
+    "QKV   0,2048,3840,1280": [42, 51, 65, 2062],
+    "c32   1,2048,1280,11520": [66, 42, 62, 91, 43],
+    "FF1h  0,8192,5120,640": [42, 51, 70],
+    "projh 0,8192,640,640": [42, 62, 45],
+    "FF2h  0,8192,640,2560": [42, 92, 65],
+    "c64   1,8192,640,5760": [62, 92, 42, 65],
+    "c128  1,32768,320,2880": [42, 62, 43],
 }
 
 ed = FastEditor(model_name="ssd-1b", use_full_controlnet=True, enable_cpu_offload=False)
