@@ -254,6 +254,8 @@ def main():
         barrier()
         return time.perf_counter() - t_
 
+    if nfl > 1:                                          # untimed set-up: make sure the in-flight streams really overlap
+        streams = pipe.calibrate_streams([jobs[i] for i in range(nfl)], streams, log=log)
     single = None
     if nfl > 1:                                          # reference point: one edit at a time (forked two-stream graph)
         keep, nfl = nfl, 1
@@ -334,6 +336,7 @@ def main():
     if nfl > 1:                                          # the same through worker threads, as run_batch.py --in_flight does
         from concurrent.futures import ThreadPoolExecutor
         editor.set_in_flight(nfl)
+        editor.calibrate_in_flight(first[3], first[2], strength=args.strength, guidance_scale=args.guidance, seed=42)
 
         def worker(slot, n):
             editor.worker_slot(slot)

@@ -46,6 +46,16 @@ class HipImg2ImgPipeline:
         self._host_out = {}
         self.eager_lock = threading.RLock()
         self.fork_streams = os.environ.get("FIE_NO_FORK", "0") != "1"
+        # Which hardware queue a stream lands on depends on the order in which streams are first used, and two edits in flight
+        # only overlap when their streams (and their graphs' branch streams) sit on different queues: creating the slot streams
+        # HERE, before any graph, was measured to lose the whole in-flight gain (12.5 instead of 14.4 images/s).  They are
+        # created lazily instead, and calibrate_streams() below re-draws streams when a measured pair does not overlap.
+        if ctx.device.type == "cuda" and os.environ.get("FIE_EAGER_STREAMS") == "1":    # reproducer of a bad queue mapping (tests of calibrate_streams)
+            warm = [self.slot_stream(0), self.slot_stream(1)] + ([self._side_stream()] if self.fork_streams else [])
+            for st in warm:
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=ctx.device)
+            torch.cuda.synchronize(ctx.device)
 
     # -- diffusers API surface the reference touches
     def set_progress_bar_config(self, **kw):          # run_batch.py:157-158
@@ -308,6 +318,38 @@ class HipImg2ImgPipeline:
         queues (fie_amd.py sets 16) for the streams to stay on separate queues."""
         few_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8
         return torch.cuda.Stream(device=self.ctx.device, priority=0 if equal_priority and not few_queues else -(slot % 2))
+
+    def calibrate_streams(self, jobs, streams, tries=4, log=None):
+        """Pick launch streams on which `len(jobs)` edits really overlap.  jobs[i] is replayed on slot i (its graph must exist or
+        is captured here); candidates are `streams` and up to `tries - 1` freshly drawn sets; each is timed with two rounds of
+        concurrent replays and the fastest set is returned.  Replay is stream-agnostic, so no graph is re-captured."""
+        def timed(strs):
+            torch.cuda.synchronize(self.ctx.device)
+            t0 = torch.cuda.Event(enable_timing=True)
+            t1 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+            for _ in range(2):
+                for i, (job, st) in enumerate(zip(jobs, strs)):
+                    with torch.cuda.stream(st):
+                        self.run_device_graphed(job, slot=i)
+            torch.cuda.synchronize(self.ctx.device)
+            t1.record()
+            torch.cuda.synchronize(self.ctx.device)
+            return t0.elapsed_time(t1)
+
+        for i, (job, st) in enumerate(zip(jobs, streams)):          # captures (if needed) + first replays: untimed
+            with torch.cuda.stream(st):
+                self.run_device_graphed(job, slot=i)
+        best, best_ms = list(streams), timed(streams)
+        first_ms = best_ms
+        for _ in range(tries - 1):
+            cand = [self.new_slot_stream(i, equal_priority=all(s.priority == 0 for s in streams)) for i in range(len(jobs))]
+            ms = timed(cand)
+            if ms < best_ms:
+                best, best_ms = cand, ms
+        if log:
+            log(f"stream calibration: first set {first_ms:.1f} ms, chosen {best_ms:.1f} ms for 2 rounds of {len(jobs)} edits in flight")
+        return best
 
     def slot_stream(self, slot):
         """Stream of graph slot `slot`.  Every slot, slot 0 included, owns a stream: replaying an edit's graph on the legacy

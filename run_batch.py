@@ -120,6 +120,17 @@ def process_shard(editor, entries, args, edited_dir, comparisons_dir, progress=N
         return _process_entries(editor, entries, args, edited_dir, comparisons_dir, progress)
     from concurrent.futures import ThreadPoolExecutor
     editor.set_in_flight(n)
+    if hasattr(editor, "calibrate_in_flight"):        # untimed set-up: pick slot streams on which the n edits really overlap
+        for _, _, entry in entries:
+            try:
+                probe = Image.open(safe_join(args.source_dir, entry["image_path"])).convert("RGB")
+                extra = {} if args.strength is None else {"strength": args.strength}
+                editor.calibrate_in_flight(probe, entry.get("editing_prompt") or "calibration", num_inference_steps=args.steps,
+                                           guidance_scale=args.guidance, controlnet_conditioning_scale=args.control_scale,
+                                           seed=args.seed, **extra)
+                break
+            except (OSError, ValueError, KeyError):
+                continue
 
     def work(slot):
         editor.worker_slot(slot)

@@ -165,6 +165,29 @@ class FastEditor:
         if self.in_flight > 1:
             self.pipe.use_graph = True
 
+    def calibrate_in_flight(self, image, prompt, **edit_kwargs):
+        """[additive] after set_in_flight(n): make sure the n slot streams really overlap on this GPU.  Which hardware queue a
+        stream gets depends on the order of stream creation in the process; when two slots share a queue the edits serialise
+        and the in-flight gain is lost.  Prepares one job per slot from (image, prompt), times concurrent replays on the current
+        slot streams and on a few freshly drawn sets, and keeps the fastest (HipImg2ImgPipeline.calibrate_streams)."""
+        if self.in_flight <= 1:
+            return
+        kw = dict(strength=0.80, num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5,
+                  canny_low_threshold=100, canny_high_threshold=200)
+        kw.update(edit_kwargs)
+        seed = kw.pop("seed", None)
+        lo, hi = kw.pop("canny_low_threshold"), kw.pop("canny_high_threshold")
+        kw.pop("negative_prompt", None)
+        with self.pipe.eager_lock:
+            src, ctl = self._canny_device(image, lo, hi, size=(1024, 1024))
+            jobs = [self.pipe.prepare(prompt, "", src, ctl, kw["strength"], kw["num_inference_steps"], kw["guidance_scale"],
+                                      kw["controlnet_conditioning_scale"],
+                                      torch.Generator(device="cpu").manual_seed(seed if seed is not None else 0))
+                    for _ in range(self.in_flight)]
+            streams = self.pipe.calibrate_streams(jobs, [self.pipe.slot_stream(i) for i in range(self.in_flight)], tries=6)
+            for i, st in enumerate(streams):
+                self.pipe._slot_streams[i] = st
+
     def worker_slot(self, slot):
         """Bind the calling thread to graph slot `slot` (0 <= slot < in_flight)."""
         self._tls.slot = int(slot)

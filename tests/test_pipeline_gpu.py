@@ -211,6 +211,7 @@ def test_two_edits_in_flight_match_serial(fie):
     imgs = [synth_image(30 + i, 96) for i in range(6)]
     serial = [np.asarray(ed.edit(im, f"a [toy] number {i}", seed=7, strength=0.5)) for i, im in enumerate(imgs)]
     ed.set_in_flight(2)
+    ed.calibrate_in_flight(imgs[0], "a [toy] number 0", seed=7, strength=0.5)      # may re-draw the slot streams; results unchanged
 
     def work(slot):
         ed.worker_slot(slot)
