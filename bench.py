@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """Headline benchmark: PIE-Bench images/sec @1024^2, SSD-1B fp16, nominal 4-step LCM img2img with Canny ControlNet
-(BASELINE.json metric; workload = configs[1]).  One "step" = one full edit of one synthetic PIE-Bench-shaped item
-(CLIP x2, VAE encode, evals x (ControlNet + UNet), CFG + LCM steps, VAE decode, u8 conversion), inputs already
-resident in HBM when the timed region starts.  Image-parallel over N GPUs: every rank edits its own items with a
-full replica; no collective inside the timed region except the bracketing barriers.
+(BASELINE.json metric; workload = configs[1]).  One "step" = one full `FastEditor.edit()` of one synthetic
+PIE-Bench-shaped item, PIL in -> PIL out, timed exactly where /root/reference/run_batch.py:208-221 puts its timer:
+LANCZOS 1024^2 + Canny + tokenise + RNG + H2D + (CLIP x2, VAE encode, evals x (ControlNet + UNet), CFG + LCM steps, VAE
+decode, u8) + D2H.  `value` = K serial edits of K different items / wall time (one edit at a time, as the reference runs).
+The device-resident hipGraph replay rate, two edits in flight and batch-N are reported as named extra keys, never as `value`.
+Image-parallel over N GPUs: every rank edits its own items with a full replica; no collective inside the timed region
+except the bracketing barriers.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        # N > 1 without a launcher: spawns its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (UNet forward, fp16 MFMA bound,
-HIP-event timed) and `cpu_baseline` (oracle/ fp32 restatement timed on this host, rank 0, N=1 only)."""
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (dominant kernel + UNet forward, fp16 MFMA
+bound, HIP-event timed) and `cpu_baseline` (oracle/ fp32 restatement timed on this host, rank 0, N=1 only)."""
 import argparse
 import csv
 import json
@@ -141,9 +144,11 @@ def time_unet_forward(pipe, job, iters=3):
 
 
 def time_dominant_kernel(pipe, nb, iters=20):
-    """The single kernel with the largest share of device time (profiles/r01_v3_bench_summary.md): the v3 GEMM
-    `gemm3_kernel<256,128,3,0,8>` on the UNet's 32x32-latent FF1 projection (M = nb*1024 tokens, N = 10240, K = 1280, bias +
-    GEGLU epilogue).  Average launch duration by HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K."""
+    """The single kernel with the largest share of device time (profiles/r02_per_edit_kernels.md): the GEMM on the UNet's
+    32x32-latent FF1 projection (M = nb*1024 tokens, N = 10240, K = 1280, bias + GEGLU epilogue).  Average launch duration by
+    HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K.  `traffic` is NOT measured here (PMC counters cannot be
+    collected inside the bench): it is read from profiles/dominant_kernel_pmc.json, which names the rocprofv3 --pmc CSVs it
+    was derived from, and is reported only when that record is for this shape."""
     from fie_amd import hip
     ctx, dev = pipe.ctx, pipe.ctx.device
     m, n, k = nb * 1024, 10240, 1280
@@ -154,6 +159,7 @@ def time_dominant_kernel(pipe, nb, iters=20):
     out = torch.empty((m, n // 2), device=dev, dtype=torch.float16)
     for _ in range(3):
         ctx.gemm(a, w, n, out=out, bias=bias, act=hip.ACT_GEGLU)
+    kernel = hip.last_gemm_kernel()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -162,28 +168,60 @@ def time_dominant_kernel(pipe, nb, iters=20):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     tf = 2.0 * m * n * k / (us * 1e-6) / 1e12
-    # fabric-side bytes per launch from the rocprofv3 --pmc passes of this shape + epilogue (profiles/r01_dominant_kernel_summary.md,
-    # counter CSVs next to it): 2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE.  Static: PMC cannot run inside the bench.
-    traffic_mb = 2 * 110460 * 1024 / 1e6 + 20480 * 1024 / 1e6 if (m, n, k) == (2048, 10240, 1280) else None
-    return {"kernel": "gemm3_kernel<256,128,3,0,8> (FF1 GEGLU projection, 32x32 latents)", "shape": {"M": m, "N": n, "K": k},
+    traffic_mb, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "dominant_kernel_pmc.json")) as f:
+            rec = json.load(f)
+        if [rec["shape"]["M"], rec["shape"]["N"], rec["shape"]["K"]] == [m, n, k]:
+            # gfx950: FETCH_SIZE counts a wide coalesced read at half its bytes (MI355X_MICROARCH.md, HBM) -> 2 x FETCH + WRITE
+            traffic_mb = round((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024 / 1e6, 1)
+            traffic_src = rec.get("source")
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"kernel": f"{kernel} (FF1 GEGLU projection, 32x32 latents)", "shape": {"M": m, "N": n, "K": k},
             "avg_us": round(us, 2), "launches": iters, "achieved": round(tf, 1), "frac": round(tf / PEAK_F16_DENSE_TFLOPS, 4),
             "algorithmic_gflop_per_launch": round(2.0 * m * n * k / 1e9, 2),
             "algorithmic_mb_per_launch": round((m * k + n * k + m * n // 2) * 2 / 1e6, 1),
-            "traffic_mb_per_launch": None if traffic_mb is None else round(traffic_mb, 1)}
+            "traffic_mb_per_launch": traffic_mb, "traffic_source": traffic_src}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (torch.distributed.run, one process
+    per GPU, rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, and exit with the launcher's code.
+    On a box with fewer than N GPUs this is a rehearsal: gloo backend, ranks folded onto the available devices (at most 6
+    processes may share one card on the pool's boxes)."""
+    import socket
+    import subprocess
+    ngpu = torch.cuda.device_count()                 # does not initialise HIP on this image
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ngpu < args.gpus:
+        if ngpu == 0 or args.gpus > 6 * ngpu:
+            raise SystemExit(f"--gpus {args.gpus}: only {ngpu} GPU(s) visible and at most 6 ranks may share one")
+        env["FIE_DIST_BACKEND"] = "gloo"
+        log(f"{ngpu} GPU(s) for {args.gpus} ranks: gloo rehearsal, ranks share devices")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="ssd-1b", choices=["ssd-1b", "sdxl"])
     ap.add_argument("--controlnet", default="full", choices=["full", "small"])
     ap.add_argument("--strength", type=float, default=0.5)
     ap.add_argument("--guidance", type=float, default=1.5)
+    ap.add_argument("--weights", default="f16", choices=["f16", "f8e4m3"], help="f8e4m3: BASELINE config 5 (separate config, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2, help="edits in flight per GPU (independent hipGraph slots on separate streams)")
-    ap.add_argument("--batch", type=int, default=0, help="also time N images per device job (BASELINE config 'batch=8'); reported as "
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (skip the device-resident / in-flight / batch extras)")
+    ap.add_argument("--in-flight", type=int, default=2, help="extras: edits in flight per GPU (independent hipGraph slots on separate streams)")
+    ap.add_argument("--batch", type=int, default=0, help="extras: also time N images per device job (BASELINE config 'batch=8'); reported as "
                                                          "batched_images_per_sec, never as `value`")
     ap.add_argument("--no-graph", action="store_true", help="issue the launches eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
@@ -191,8 +229,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a launcher with WORLD_SIZE={args.gpus} (torch.distributed.run)")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit(self_launch(args))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     dev_index = local % torch.cuda.device_count()      # == local on a real N-GPU node; folds ranks in a one-GPU gloo rehearsal
     torch.cuda.set_device(dev_index)
     dist = None
@@ -207,61 +247,46 @@ def main():
     import io
     from src.pipeline import FastEditor
     from fie_amd import flops
+    ekw = {}
+    if args.weights != "f16":
+        ekw["weight_dtype"] = args.weights
     with contextlib.redirect_stdout(io.StringIO() if rank else sys.stderr):
         editor = FastEditor(model_name=args.model, device=f"cuda:{dev_index}" if world > 1 else "cuda",
-                            enable_cpu_offload=False, use_full_controlnet=args.controlnet == "full")
+                            enable_cpu_offload=False, use_full_controlnet=args.controlnet == "full", **ekw)
     pipe = editor.pipe
+    pipe.use_graph = not args.no_graph
     cfgs = pipe.cfgs
     items = load_items()
     total = args.warmup + args.steps
 
-    # image-parallel shard: rank r takes items r, r+W, ...; weak scaling = K items per rank
-    from PIL import Image
-    jobs, first = [], None
+    # image-parallel shard: rank r takes items r, r+W, ...; weak scaling = K DIFFERENT items per rank.  The source
+    # images are decoded PIL images in host memory, as at run_batch.py:199 (image open / JPEG decode is outside the timer there)
+    work = []
     for s in range(total):
         it = items[(rank + s * world) % len(items)]
-        src = synth_item_image(int(it["image_id"]) % 100000 + s)
-        inp = src.resize((1024, 1024), Image.LANCZOS)
-        ctrl = editor.preprocess_image(inp)
-        gen = torch.Generator(device="cpu").manual_seed(42)
-        jobs.append(pipe.prepare(it["editing_prompt"], "", inp, ctrl, args.strength, 4, args.guidance, 0.5, gen))
-        if first is None:
-            first = (inp, ctrl, it["editing_prompt"], src)
-    torch.cuda.synchronize()
-    log(f"{total} jobs resident on the device; warmup {args.warmup}, timed {args.steps}")
+        work.append((synth_item_image(int(it["image_id"]) % 100000 + s), it["editing_prompt"]))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    nfl = 1 if args.no_graph else max(1, args.in_flight)
-    streams = [pipe.new_slot_stream(i, equal_priority=True) for i in range(nfl)]
+    def edit(s):
+        # exactly the call of run_batch.py:209-219 (PIL in -> PIL out: LANCZOS 1024^2, Canny, tokenise, RNG, H2D, CLIP x2, VAE
+        # encode, evals x (ControlNet + UNet), CFG + LCM steps, VAE decode, u8, D2H); strength is the additive flag
+        return editor.edit(work[s][0], work[s][1], negative_prompt="", strength=args.strength, num_inference_steps=4,
+                           guidance_scale=args.guidance, controlnet_conditioning_scale=0.5, seed=42)
 
-    def run(job, s):
-        if args.no_graph:
-            return pipe.run_device(job)
-        with torch.cuda.stream(streams[s % nfl]):       # up to `in_flight` edits overlap on the GPU, one graph slot each
-            return pipe.run_device_graphed(job, slot=s % nfl)
-
-    def timed_pass():
-        for s in range(args.warmup):
-            run(jobs[s], s)
-        barrier()
-        t_ = time.perf_counter()
-        for s in range(args.warmup, total):
-            run(jobs[s], s)
-        barrier()
-        return time.perf_counter() - t_
-
-    if nfl > 1:                                          # untimed set-up: make sure the in-flight streams really overlap
-        streams = pipe.calibrate_streams([jobs[i] for i in range(nfl)], streams, log=log)
-    single = None
-    if nfl > 1:                                          # reference point: one edit at a time (forked two-stream graph)
-        keep, nfl = nfl, 1
-        single = timed_pass()
-        nfl = keep
-    elapsed = timed_pass()
+    # ---- HEADLINE: K serial edits, one at a time, timer placed as run_batch.py:208-221 (sum over the K calls)
+    for s in range(args.warmup):
+        edit(s)                                        # first call captures the hipGraph, allocates Canny / resize tables
+    barrier()
+    t_ = time.perf_counter()
+    for s in range(args.warmup, total):
+        out_img = edit(s)
+    barrier()
+    elapsed = time.perf_counter() - t_
+    assert out_img.size == (1024, 1024)
     per_rank = [elapsed]
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else "cuda", dtype=torch.float64)
@@ -269,106 +294,138 @@ def main():
         dist.all_gather(g, t)                      # C2: gather of per-rank timings (metrics) on every rank
         per_rank = [float(x.item()) for x in g]
         elapsed = max(per_rank)
-
-    log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
+    log(f"timed region: {elapsed:.3f}s for {args.steps} serial PIL-in -> PIL-out edits")
     evals, nb = pipe.last_stats["unet_evals"], pipe.last_stats["cfg_batch"]
     value = args.steps * world / elapsed
 
-    batched = None
-    if args.batch > 1 and not args.no_graph:              # N images per job: UNet / ControlNet / CLIP at batch N x CFG
-        items_b = [items[(rank + s * world) % len(items)] for s in range(args.batch)]
-        imgs_b = [synth_item_image(int(it["image_id"]) % 100000 + s).resize((1024, 1024), Image.LANCZOS) for s, it in enumerate(items_b)]
-        ctrl_b = [editor.preprocess_image(im) for im in imgs_b]
-        gens = [torch.Generator(device="cpu").manual_seed(42) for _ in imgs_b]
-        jb = pipe.prepare_batch([it["editing_prompt"] for it in items_b], None, imgs_b, ctrl_b, args.strength, 4, args.guidance, 0.5, gens)
-        with torch.cuda.stream(streams[0]):
-            pipe.run_device_graphed(jb)
-            barrier()
-            t_ = time.perf_counter()
-            for _ in range(3):
-                pipe.run_device_graphed(jb)
-            barrier()
-        batched = 3 * args.batch * world / (time.perf_counter() - t_)
-        log(f"batch {args.batch}: {batched:.2f} images/s")
+    # ---- extras (named keys, never `value`): device-resident hipGraph replay, two edits in flight, batch N
+    extras = {}
+    from PIL import Image
+    first_src, first_prompt = work[args.warmup % total]
+    first_inp = first_src.resize((1024, 1024), Image.LANCZOS)
+    first_ctrl = editor.preprocess_image(first_inp)
+    if not args.no_extras and not args.no_graph:
+        nrep = min(args.steps, 8)
+        jobs = []
+        for s in range(nrep + 2):
+            src, prompt = work[s % total]
+            inp = src.resize((1024, 1024), Image.LANCZOS)
+            gen = torch.Generator(device="cpu").manual_seed(42)
+            jobs.append(pipe.prepare(prompt, "", inp, editor.preprocess_image(inp), args.strength, 4, args.guidance, 0.5, gen))
+        torch.cuda.synchronize()
+        nfl = max(1, args.in_flight)
+        streams = [pipe.new_slot_stream(i, equal_priority=True) for i in range(nfl)]
+        if nfl > 1:                                          # untimed set-up: make sure the in-flight streams really overlap
+            streams = pipe.calibrate_streams([jobs[i] for i in range(nfl)], streams, log=log)
 
-    # ---- roofline of the UNet forward, HIP-event timed on the launch stream (2 extra untimed-for-throughput passes)
+        def replay_pass(n_streams):
+            for s in range(2):
+                with torch.cuda.stream(streams[s % n_streams]):
+                    pipe.run_device_graphed(jobs[s], slot=s % n_streams)
+            barrier()
+            t0 = time.perf_counter()
+            for s in range(2, nrep + 2):
+                with torch.cuda.stream(streams[s % n_streams]):
+                    pipe.run_device_graphed(jobs[s], slot=s % n_streams)
+            barrier()
+            return nrep * world / (time.perf_counter() - t0)
+
+        extras["device_resident_images_per_sec"] = round(replay_pass(1), 4)
+        if nfl > 1:
+            extras["device_resident_in_flight_images_per_sec"] = {"in_flight": nfl, "value": round(replay_pass(nfl), 4)}
+            from concurrent.futures import ThreadPoolExecutor
+            editor.set_in_flight(nfl)
+            editor.calibrate_in_flight(first_src, first_prompt, strength=args.strength, guidance_scale=args.guidance, seed=42)
+            per = max(2, args.steps // nfl)
+
+            def worker(slot, lo, n):
+                editor.worker_slot(slot)
+                for s in range(n):
+                    edit((lo + s * nfl + slot) % total)
+
+            with ThreadPoolExecutor(max_workers=nfl) as pool:
+                list(pool.map(lambda sl: worker(sl, 0, 1), range(nfl)))          # capture the per-slot graphs
+                barrier()
+                t1 = time.perf_counter()
+                list(pool.map(lambda sl: worker(sl, args.warmup, per), range(nfl)))
+                barrier()
+                extras["e2e_in_flight_images_per_sec"] = {"in_flight": nfl, "value": round(per * nfl * world / (time.perf_counter() - t1), 4)}
+            editor.set_in_flight(1)
+            editor.worker_slot(0)
+        if args.batch > 1:                                   # N images per job: UNet / ControlNet / CLIP at batch N x CFG
+            srcs = [work[s % total][0] for s in range(args.batch)]
+            prompts = [work[s % total][1] for s in range(args.batch)]
+            editor.edit_batch(srcs, prompts, strength=args.strength, guidance_scale=args.guidance, seed=42)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                editor.edit_batch(srcs, prompts, strength=args.strength, guidance_scale=args.guidance, seed=42)
+            barrier()
+            extras["batched_images_per_sec"] = {"batch": args.batch, "what": "PIL in -> PIL out, edit_batch()",
+                                                "value": round(3 * args.batch * world / (time.perf_counter() - t0), 4)}
+        log(f"extras: {extras}")
+
+    # ---- roofline of the UNet forward, HIP-event timed on the launch stream (untimed-for-throughput passes)
+    gen = torch.Generator(device="cpu").manual_seed(42)
+    job0 = pipe.prepare(first_prompt, "", first_inp, first_ctrl, args.strength, 4, args.guidance, 0.5, gen)
     stage = {}
     for s in range(2):
         pipe.timing = []
-        pipe.run_device(jobs[args.warmup + s % max(args.steps, 1)])
+        pipe.run_device(job0)
         for k, v in pipe.stage_ms().items():
             stage[k] = stage.get(k, 0.0) + v / 2
     pipe.timing = None
     dominant = time_dominant_kernel(pipe, nb)
     fl = flops.image_flops(cfgs, evals, nb)
     # roofline pass: UNet alone on one stream (the overlapped production schedule interleaves ControlNet kernels)
-    unet_ms_per_fwd = time_unet_forward(pipe, jobs[args.warmup])
+    unet_ms_per_fwd = time_unet_forward(pipe, job0)
     unet_tflops = fl["unet"] * nb / (unet_ms_per_fwd * 1e-3) / 1e12
     image_tflops = fl["total"] / (sum(stage.values()) * 1e-3) / 1e12
 
-    # ---- end-to-end (PIL in -> PIL out: LANCZOS, Canny, H2D, device, D2H) as run_batch.py:208-221 times it
-    def edit_once():
-        editor.edit(first[3], first[2], strength=args.strength, guidance_scale=args.guidance, seed=42)
-
-    edit_once()                                          # first call: Canny workspace, PIL filter tables
+    # ---- where one serial edit's host time goes (4 more edits with the three host-side stages wrapped)
     marks = {}
 
     def wrap(obj, name):
         fn = getattr(obj, name)
 
         def timed(*a, **k):
-            t_ = time.perf_counter()
+            t0 = time.perf_counter()
             r = fn(*a, **k)
-            marks[name] = marks.get(name, 0.0) + (time.perf_counter() - t_) * 1e3 / 4
+            marks[name] = marks.get(name, 0.0) + (time.perf_counter() - t0) * 1e3 / 4
             return r
         setattr(obj, name, timed)
         return fn
 
-    saved = [(o, n, wrap(o, n)) for o, n in ((editor, "_canny_device"), (pipe, "prepare"), (pipe, "run_device_graphed"))]
+    saved = [(o, n, wrap(o, n)) for o, n in ((editor, "_canny_device"), (pipe, "prepare"), (pipe, "run_device_graphed"), (pipe, "_to_host"))]
     t1 = time.perf_counter()
     for s in range(4):
-        edit_once()
-    e2e = (time.perf_counter() - t1) / 4
+        edit(args.warmup + s % max(args.steps, 1))
+    e2e_ms = (time.perf_counter() - t1) / 4 * 1e3
     for o, n, fn in saved:
         setattr(o, n, fn)
-    log(f"e2e host ms/edit: { {k: round(v, 1) for k, v in marks.items()} } of {e2e * 1e3:.1f}")
-    e2e_nfl = None
-    if nfl > 1:                                          # the same through worker threads, as run_batch.py --in_flight does
-        from concurrent.futures import ThreadPoolExecutor
-        editor.set_in_flight(nfl)
-        editor.calibrate_in_flight(first[3], first[2], strength=args.strength, guidance_scale=args.guidance, seed=42)
-
-        def worker(slot, n):
-            editor.worker_slot(slot)
-            for _ in range(n):
-                edit_once()
-
-        with ThreadPoolExecutor(max_workers=nfl) as pool:
-            list(pool.map(lambda sl: worker(sl, 1), range(nfl)))          # capture the per-slot graphs
-            t1 = time.perf_counter()
-            list(pool.map(lambda sl: worker(sl, 4), range(nfl)))
-            e2e_nfl = (time.perf_counter() - t1) / (4 * nfl)
-        editor.set_in_flight(1)
-    log(f"stage ms: { {k: round(v, 1) for k, v in stage.items()} }; e2e {e2e * 1e3:.1f} ms/image")
+    log(f"stage ms: { {k: round(v, 1) for k, v in stage.items()} }; host ms/edit { {k: round(v, 1) for k, v in marks.items()} } of {e2e_ms:.1f}")
 
     if rank == 0:
         out = {
             "metric": "PIE-Bench images/sec @1024^2 SSD-1B fp16 4-step", "value": round(value, 4), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.weights == "f16" else "f16 activations, f8e4m3 weights",
             "data": "synthetic (seeded PIE-Bench-shaped 512^2 images, real PIE-Bench prompts, seeded random-init weights, stand-in tokenizer)",
+            "timed_region": "K serial FastEditor.edit() calls on K different items, PIL in -> PIL out, timer placed as run_batch.py:208-221 "
+                            "(includes LANCZOS, Canny, tokenise, RNG, H2D, the device graph, D2H, PIL); excludes model load and image decode",
             "config": {"workload": f"{args.model} fp16 + ControlNet-Canny({args.controlnet}) LCM img2img, num_inference_steps=4, "
-                                   f"strength={args.strength}, guidance={args.guidance}, 1024x1024, batch=1 image per GPU",
+                                   f"strength={args.strength}, guidance={args.guidance}, 1024x1024, batch=1 image per GPU, one edit at a time",
                        "unet_preset": cfgs["unet"]["name"], "controlnet_preset": cfgs["controlnet"]["name"],
-                       "unet_evals": evals, "cfg_batch": nb, "parallelism": f"image-parallel x{world}", "launch": "eager" if args.no_graph else "hipGraph replay", "in_flight_per_gpu": nfl,
+                       "unet_evals": evals, "cfg_batch": nb, "parallelism": f"image-parallel x{world}",
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "weights": args.weights,
                        "tflop_per_image": round(fl["total"] / 1e12, 2)},
-            # the dominant kernel (largest share of device time in profiles/r01_final_bench_summary.md), HIP-event timed above;
-            # the whole UNet forward (every launch between the events bracketing unet.encode + unet.decode, alone on one
-            # stream) is priced against the same peak next to it
+            # the dominant kernel (largest share of device time in profiles/), HIP-event timed above; the whole UNet forward
+            # (every launch between the events bracketing unet.encode + unet.decode, alone on one stream) is priced beside it
             "roofline": {"bound": "mfma", "kernel": dominant["kernel"], "shape": dominant["shape"],
                          "achieved": dominant["achieved"], "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dominant["frac"], "traffic": dominant["traffic_mb_per_launch"], "traffic_unit": "MB/launch (L2-miss side: "
-                         "2 x FETCH_SIZE + WRITE_SIZE; the operands fit the Infinity Cache)",
+                         "frac": dominant["frac"], "traffic": dominant["traffic_mb_per_launch"],
+                         "traffic_unit": "MB/launch, fabric side: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes",
+                         "traffic_source": dominant["traffic_source"],
                          "avg_us": dominant["avg_us"], "launches": dominant["launches"],
                          "algorithmic_gflop_per_launch": dominant["algorithmic_gflop_per_launch"],
                          "algorithmic_mb_per_launch": dominant["algorithmic_mb_per_launch"],
@@ -376,16 +433,15 @@ def main():
                                           "frac": round(unet_tflops / PEAK_F16_DENSE_TFLOPS, 4),
                                           "algorithmic_tflop": round(fl["unet"] * nb / 1e12, 3), "ms": round(unet_ms_per_fwd, 3)}},
             "stage_ms": {k: round(v, 2) for k, v in stage.items()},
+            "host_ms_per_edit": {k: round(v, 2) for k, v in marks.items()},
             "image_tflops": round(image_tflops, 2),
-            "batched_images_per_sec": None if batched is None else {"batch": args.batch, "value": round(batched, 4)},
-            "e2e_images_per_sec": round(1.0 / e2e, 4),
-            "e2e_in_flight_images_per_sec": None if e2e_nfl is None else round(1.0 / e2e_nfl, 4),
             "per_rank_seconds": [round(x, 4) for x in per_rank],
-            "single_stream_images_per_sec": round(args.steps * world / single, 4) if single else None,
+            "dist_backend": None if dist is None else dist.get_backend(),
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(editor, cfgs, first[:3], evals, nb)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(editor, cfgs, (first_inp, first_ctrl, first_prompt), evals, nb)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

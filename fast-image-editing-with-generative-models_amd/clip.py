@@ -9,6 +9,15 @@ from . import hip
 from .nn import Linear, Norm, F16, _dev
 
 
+def eos_positions(ids, eos_token_id):
+    """Column of the pooled token per row (modeling_clip.py:561-582 of the local transformers): legacy configs with
+    eos_token_id == 2 (as shipped with SDXL's text encoders) take argmax(ids) -- <|endoftext|> is the largest id of the CLIP
+    vocabulary --, newer ones the first occurrence of eos_token_id."""
+    if eos_token_id == 2:
+        return ids.argmax(dim=-1)
+    return (ids == eos_token_id).int().argmax(dim=-1)
+
+
 class ClipText:
     def __init__(self, ctx, cfg, sd):
         self.ctx, self.cfg = ctx, cfg
@@ -51,7 +60,7 @@ class ClipText:
         if self.proj is not None:
             last = ctx.layernorm(x, self.final_ln.g, self.final_ln.b, cfg["eps"])
             if eos_rows is None:                                                  # first EOS (host index logic)
-                eos = (ids.to("cpu") == cfg["eos_token_id"]).int().argmax(dim=-1)
+                eos = eos_positions(ids.to("cpu"), cfg["eos_token_id"])
                 eos_rows = (torch.arange(b) * t + eos).to(ctx.device)
             pooled = self.proj(ctx, last.index_select(0, eos_rows))
         return penult, pooled

@@ -1256,6 +1256,7 @@ struct TileOverride { int mode, M, N, K, code; };
 TileOverride g_overrides[32];
 int g_n_overrides = 0;
 
+thread_local char g_last_kernel[96] = "";     // what the last launch<> of this thread chose (bench.py names the roofline kernel with it)
 int g_force_order = -1;  // tuning hook: -1 = estimate, 0 / 1 = force the tile order
 int g_force_tile = 0;   // tuning hook (fie_debug_force_tile): 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64
 
@@ -1352,6 +1353,7 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
                 "bad tile code %d", code);
     a.nbm = (a.M + bm - 1) / bm;
     a.nbn = (a.N + bn - 1) / bn;
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s tile code %d (%dx%d)", MODE == 1 ? "conv3x3" : "gemm", code, bm, bn);
     {
         // Which operand should stay resident in an XCD's 4 MiB L2?  Consecutive tile ids run on one XCD, so the fastest
         // tile index decides what is re-streamed from the Infinity Cache / HBM.  Estimate both orders' traffic.
@@ -1505,6 +1507,8 @@ int fie_debug_tile_override(const char* spec) {
     }
     return g_n_overrides;
 }
+
+const char* fie_debug_last_gemm_kernel(void) { return g_last_kernel; }
 
 int fie_debug_extra_lds(int bytes) {
     g_extra_lds = bytes < 0 ? 0 : bytes;

@@ -58,6 +58,7 @@ SIGNATURES = {
     "fie_debug_gn_onepass": [_I],
     "fie_debug_extra_lds": [_I],
     "fie_debug_tile_override": [_c.c_char_p],
+    "fie_debug_last_gemm_kernel": [],
 }
 
 _lib = None
@@ -86,7 +87,13 @@ def lib():
             fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes") else _I
         _lib.fie_last_error.restype = ctypes.c_char_p
         _lib.fie_last_error.argtypes = []
+        _lib.fie_debug_last_gemm_kernel.restype = ctypes.c_char_p
     return _lib
+
+
+def last_gemm_kernel():
+    """Kernel / tile the last GEMM or conv launch of this thread used (names the roofline kernel in bench.py)."""
+    return lib().fie_debug_last_gemm_kernel().decode()
 
 
 class FieError(RuntimeError):

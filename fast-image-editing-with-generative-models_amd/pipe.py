@@ -11,7 +11,7 @@ import torch
 from PIL import Image
 
 from . import hip
-from .clip import ClipText
+from .clip import ClipText, eos_positions
 from .lcm import LCMSchedule
 from .nn import ControlNet, UNet
 from .presets import LCM_SCHED
@@ -38,7 +38,15 @@ class HipImg2ImgPipeline:
         self.last_stats = {}
         self.timing = None         # set to [] to collect per-stage HIP-event timings in run_device()
         self.use_graph = os.environ.get("FIE_NO_GRAPH", "0") != "1"
-        self._graphs = {}          # never pruned: destroying a graph and capturing another gave a slow graph (121 vs 81 ms)
+        # hipGraph cache, bounded: key = (size, CFG batch, step plan, guidance, control scale, slot, images); at most MAX_GRAPHS
+        # keys are captured (insertion-ordered dict, least recently used first); a key beyond the cap runs EAGERLY instead of
+        # evicting -- destroying a graph and capturing another one was measured to give a slow graph (121 vs 81 ms), and a
+        # parameter sweep must not grow HBM without bound.  All graphs of a slot share one capture memory pool (a slot
+        # replays one graph at a time and its output is consumed before the next replay), so k keys cost one pool, not k.
+        self._graphs = {}
+        self._pools = {}
+        self.max_graphs = int(os.environ.get("FIE_MAX_GRAPHS", "12"))
+        self.eager_overflow = 0     # calls served eagerly because the cache was full
         self._side = None
         self._slot_streams = {}
         self._n_forked = 0
@@ -111,7 +119,7 @@ class HipImg2ImgPipeline:
         n_noise = 2 + sum(1 for st in steps if not st["last"])
         nb = 2 if do_cfg else 1
         ids_g = self.tok_g(texts)
-        eos = (ids_g == self.cfgs["clip_g"]["eos_token_id"]).int().argmax(dim=-1)       # first EOS per row
+        eos = eos_positions(ids_g, self.cfgs["clip_g"]["eos_token_id"])                 # pooled-token column per row
         return dict(
             ids_l=self.tok_l(texts).to(dev, torch.int32), ids_g=ids_g.to(dev, torch.int32),
             eos_rows=(torch.arange(nb) * ids_g.shape[1] + eos).to(dev),
@@ -245,6 +253,7 @@ class HipImg2ImgPipeline:
         self._mark("vae_decode")
         self.last_stats = dict(unet_evals=len(steps), cfg_batch=nb, latent_hw=(lh, lw), images=n)
         self._latents = latents
+        job["_result"] = dict(stats=dict(self.last_stats), latents=latents)     # what THIS job produced (graph entries keep theirs)
         return out_u8
 
     MAX_FORKED_GRAPHS = 6
@@ -268,12 +277,17 @@ class HipImg2ImgPipeline:
             with self.eager_lock:                       # eager launches + capture go through the one C-ABI context
                 entry = self._graphs.get(key)
                 if entry is None:
+                    if len(self._graphs) >= self.max_graphs:
+                        self.eager_overflow += 1
+                        return self.run_device(job)     # cache full: serve this parameter set eagerly (see __init__)
                     self._fork_override = fork           # read by _side_stream() during this capture only
                     try:
                         entry = self._capture(key, job, slot)
                     finally:
                         self._fork_override = None
                     self._n_forked += int(fork)
+        else:
+            self._graphs[key] = self._graphs.pop(key)    # most recently used last
         graph, static, out = entry
         if static is not job:
             for k in self._TENSOR_KEYS:
@@ -281,6 +295,8 @@ class HipImg2ImgPipeline:
             for d, s_ in zip(static["noises"], job["noises"]):
                 d.copy_(s_, non_blocking=True)
         graph.replay()
+        job["_result"] = static["_result"]               # the replayed entry's own latents buffer / stats
+        self.last_stats = dict(static["_result"]["stats"])
         return out
 
     def _capture(self, key, job, slot):
@@ -294,8 +310,11 @@ class HipImg2ImgPipeline:
         self.run_device(static)                     # eager warm-up: lazy workspaces / function attributes
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
+        pool = self._pools.get(slot)
+        if pool is None:
+            pool = self._pools[slot] = torch.cuda.graph_pool_handle()
         # thread_local: other worker threads keep replaying / allocating on their own streams during this capture
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
             out = self.run_device(static)
         self.ctx.ws_tag = 0
         self.timing = timing
@@ -400,8 +419,9 @@ class HipImg2ImgPipeline:
                            guidance_scale, controlnet_conditioning_scale, generator)
         out_u8 = self.run_device_graphed(job, slot) if self.use_graph else self.run_device(job)
         if output_type == "latent":
-            lh, lw = self.last_stats["latent_hw"]
-            return types.SimpleNamespace(images=[self._latents.view(lh, lw, 4).clone()])
+            res = job["_result"]
+            lh, lw = res["stats"]["latent_hw"]
+            return types.SimpleNamespace(images=[res["latents"].view(lh, lw, 4).clone()])
         arr = self._to_host(out_u8, slot)              # device -> host sync, as `.images[0]` implies upstream
         if output_type == "np":
             return types.SimpleNamespace(images=[arr])

@@ -90,7 +90,7 @@ def _tiny(unet_like):
     c["down_attn"] = ((0, 0), (1, 1), (2, 2)) if c["mid_attn"] else ((0, 0), (1, 1), (2, 1))
     if c["kind"] == "unet":
         c["up_attn"] = ((2, 1, 2), (1, 1, 1), (0, 0, 0))
-    c["mid_attn"] = 1 if c["mid_attn"] else 0
+    c["mid_attn"] = 2 if c["mid_attn"] else 0       # = first depth of the last down block: the only mid depth a diffusers config.json can express
     if c["kind"] == "controlnet":
         c["conditioning_embedding_out_channels"] = (16, 32, 32, 64)
     return c

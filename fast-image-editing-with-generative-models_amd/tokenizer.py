@@ -1,13 +1,25 @@
 """Tokenisation for the two CLIP text encoders (upstream CLIPTokenizer; reached from encode_prompt()).
 
 The CLIP BPE vocabulary is not in the reference tree nor in this image, so two tokenizers exist:
-  * BpeTokenizer(vocab.json, merges.txt) -- the real byte-level BPE, used when a weights directory supplies the files
+  * BpeTokenizer(vocab.json, merges.txt) -- the real byte-level BPE, used when a weights directory supplies the files.
+                                             Restates the installed transformers CLIPTokenizer (tokenization_clip.py: NFC,
+                                             whitespace collapse, lower-case, the \\p{L} / \\p{N} split pattern, byte-level
+                                             alphabet, `</w>` end-of-word merges, unknown pieces -> unk = <|endoftext|>) and is
+                                             pinned against it on a synthetic vocabulary: tests/golden/bpe_*.json,
+                                             tests/test_host_cpu.py.  (transformers 4.57's slow tokenizer additionally ran
+                                             ftfy / BasicTokenizer cleaning; on plain prompts such as PIE-Bench's it agrees.)
   * StandInTokenizer                      -- deterministic stand-in (SURVEY 8d "Tokens"): BOS, one id per whitespace
                                              word = crc32(word) mod 49406, EOS, padded to 77.  "synthetic tokenisation".
 Both truncate to 77 and pad with `pad_id` (49407 for encoder 1, 0 for encoder 2)."""
 import json
 import re
+import unicodedata
 import zlib
+
+try:                    # \p{L} / \p{N} classes need the third-party `regex` module (installed with transformers)
+    import regex as _re_u
+except ImportError:     # pragma: no cover
+    _re_u = None
 
 import torch
 
@@ -52,7 +64,12 @@ class BpeTokenizer:
         self.ranks = {m: i for i, m in enumerate(merges)}
         self.b2u = _bytes_to_unicode()
         self.pad_id = pad_id
-        self.pat = re.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[a-zA-Z]+|[0-9]|[^\sa-zA-Z0-9]+")
+        self.bos = self.vocab.get("<|startoftext|>", BOS)
+        self.eos = self.unk = self.vocab.get("<|endoftext|>", EOS)
+        if _re_u is not None:
+            self.pat = _re_u.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+")
+        else:           # ASCII approximation of the classes (identical on ASCII prompts)
+            self.pat = re.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[^\W\d_]+|\d|[^\s\w]+|_+")
         self.cache = {}
 
     def _bpe(self, token):
@@ -82,11 +99,14 @@ class BpeTokenizer:
             texts = [texts]
         out = torch.full((len(texts), MAXLEN), self.pad_id, dtype=torch.int64)
         for i, t in enumerate(texts):
-            t = re.sub(r"\s+", " ", t.strip()).lower()
-            ids = [BOS]
+            t = re.sub(r"\s+", " ", unicodedata.normalize("NFC", t)).lower()
+            ids = [self.bos]
             for tok in self.pat.findall(t):
+                if tok in ("<|startoftext|>", "<|endoftext|>"):
+                    ids.append(self.vocab.get(tok, self.unk))
+                    continue
                 tok = "".join(self.b2u[b] for b in tok.encode("utf-8"))
-                ids += [self.vocab[p] for p in self._bpe(tok)]
-            ids = ids[: MAXLEN - 1] + [EOS]
+                ids += [self.vocab.get(p, self.unk) for p in self._bpe(tok)]
+            ids = ids[: MAXLEN - 1] + [self.eos]
             out[i, : len(ids)] = torch.tensor(ids)
         return out

@@ -244,26 +244,90 @@ def empty_state_dict(cfg, device="cpu", dtype=torch.float32):
     return {name: torch.empty(shape, device=device, dtype=dtype) for name, shape, _ in param_table(cfg)}
 
 
-def fold_lora(sd, lora_sd, scale=1.0):
-    """W += scale * (alpha/r) * B @ A for every PEFT-style pair found.
-    Accepts keys ``<module>.lora_A.weight`` / ``<module>.lora_B.weight`` (+ optional ``<module>.alpha``)."""
-    n = 0
-    for k in list(lora_sd):
-        if not k.endswith(".lora_A.weight"):
+LORA_FILE_NAMES = ("pytorch_lora_weights.safetensors", "lcm_lora.safetensors")       # hub name first (latent-consistency/lcm-lora-sdxl)
+
+
+def _lora_pairs(lora_sd, module_names):
+    """Group a LoRA state dict into {module: (A/down, B/up, alpha or None)} for the UNet, whatever the key scheme:
+
+      * PEFT / current diffusers:   [unet.]<module>.lora_A.weight / .lora_B.weight  (+ optional <module>.alpha)
+      * older diffusers:            [unet.]<module>.lora.down.weight / .lora.up.weight, and the attention-processor form
+                                    <block>.processor.to_q_lora.down.weight -> module <block>.to_q
+      * kohya (sd-scripts):         lora_unet_<module with '.' -> '_'>.lora_down.weight / .lora_up.weight / .alpha
+
+    `module_names` (the target state dict's module paths) resolves the kohya underscore names.  Text-encoder adapters
+    (`text_encoder.`, `lora_te1_`, `lora_te2_`) are not part of the reference's LCM-LoRA and are skipped.  Returns
+    (pairs, skipped_keys); unet-looking keys that resolve to no module raise."""
+    flat = {m.replace(".", "_"): m for m in module_names}
+    pairs, skipped, unresolved = {}, [], []
+    suffixes = ((".lora_A.weight", "a"), (".lora_B.weight", "b"), (".lora.down.weight", "a"), (".lora.up.weight", "b"),
+                (".lora_down.weight", "a"), (".lora_up.weight", "b"), (".lora_A.default.weight", "a"),
+                (".lora_B.default.weight", "b"), (".down.weight", "a"), (".up.weight", "b"), (".alpha", "alpha"))
+    for k, v in lora_sd.items():
+        role = None
+        for suf, r in suffixes:
+            if k.endswith(suf):
+                base, role = k[: -len(suf)], r
+                break
+        if role is None:
+            skipped.append(k)
             continue
-        base = k[: -len(".lora_A.weight")]
-        a = lora_sd[k].float()
-        b = lora_sd[base + ".lora_B.weight"].float()
+        if base.startswith(("text_encoder", "lora_te")):
+            skipped.append(k)
+            continue
+        if base.startswith("lora_unet_"):
+            mod = flat.get(base[len("lora_unet_"):])
+        else:
+            mod = base[len("unet."):] if base.startswith("unet.") else base
+            if ".processor." in mod and mod.endswith("_lora"):          # attn1.processor.to_q_lora -> attn1.to_q
+                mod = mod.replace(".processor.", ".")[: -len("_lora")]
+                if mod.endswith(".to_out"):
+                    mod += ".0"
+            if mod not in module_names:
+                mod = None
+        if mod is None:
+            unresolved.append(k)
+            continue
+        pairs.setdefault(mod, {})[role] = v
+    if unresolved:
+        hint = " (SGM-named kohya files, lora_unet_input_blocks_*, are not supported: convert to diffusers names)" \
+            if any("input_blocks" in k or "output_blocks" in k for k in unresolved) else ""
+        raise ValueError(f"LoRA: {len(unresolved)} keys match no UNet module, e.g. {unresolved[:3]}{hint}")
+    bad = [m for m, d in pairs.items() if "a" not in d or "b" not in d]
+    if bad:
+        raise ValueError(f"LoRA: incomplete down/up pair for {bad[:3]}")
+    return pairs, skipped
+
+
+def fold_lora(sd, lora_sd, scale=1.0):
+    """W += scale * (alpha/r) * B @ A for every adapter pair of `lora_sd` (what `pipe.load_lora_weights`,
+    /root/reference/src/pipeline.py:154, evaluates at run time through peft, folded once).  Key schemes: _lora_pairs.
+    Returns the number of folded modules."""
+    modules = {k[: -len(".weight")] for k in sd if k.endswith(".weight")}
+    pairs, _ = _lora_pairs(lora_sd, modules)
+    for mod, d in pairs.items():
+        a, b = d["a"].float(), d["b"].float()
         r = a.shape[0]
-        alpha = float(lora_sd.get(base + ".alpha", r))
-        w = sd[base + ".weight"]
+        alpha = float(d["alpha"]) if "alpha" in d else float(r)
+        w = sd[mod + ".weight"]
         if a.dim() == 4:  # conv: A is k x k (r, cin, k, k), B is 1 x 1 (cout, r, 1, 1)
             delta = torch.einsum("or,rikl->oikl", b.flatten(1), a)
         else:
             delta = b @ a
-        sd[base + ".weight"] = (w.float() + scale * (alpha / r) * delta.reshape(w.shape).to(w.device)).to(w.dtype)
-        n += 1
-    return n
+        if delta.numel() != w.numel():
+            raise ValueError(f"LoRA: {mod}: adapter shape {tuple(delta.shape)} does not fit weight {tuple(w.shape)}")
+        sd[mod + ".weight"] = (w.float() + scale * (alpha / r) * delta.reshape(w.shape).to(w.device)).to(w.dtype)
+    return len(pairs)
+
+
+def find_lora(root):
+    """The LCM-LoRA file of a weights directory: <root>/<name> or <root>/lcm_lora/<name> for the names above."""
+    for d in (root, os.path.join(root, "lcm_lora"), os.path.join(root, "lcm-lora-sdxl")):
+        for n in LORA_FILE_NAMES:
+            p = os.path.join(d, n)
+            if os.path.exists(p):
+                return p
+    return None
 
 
 def synth_lora(cfg, seed=4321, rank=8, device="cpu"):

@@ -171,6 +171,7 @@ int fie_debug_force_tile(int tile);
 int fie_debug_attn_variant(int variant);   /* 0 = default kernel, 1 = first-generation kernel (A/B benchmarking) */
 int fie_debug_tile_override(const char* spec); /* "mode,M,N,K=code;..." per-shape tile codes (whole-pipeline A/B); NULL clears; returns the count */
 int fie_debug_extra_lds(int bytes);        /* pad the v3 GEMM/conv kernels' dynamic LDS (occupancy A/B probe); 0 = off */
+const char* fie_debug_last_gemm_kernel(void); /* name / tile of the last fie_gemm_f16 / fie_conv3x3_nhwc_f16 launch of this thread */
 int fie_debug_gn_onepass(int enable);      /* 1 = default (single-pass GroupNorm on small maps), 0 = always partial/finalize/apply */
 
 /* ---- K11 Canny on the host (integer exact).  Replaces cv2.cvtColor(RGB2GRAY) + cv2.Canny at

@@ -7,6 +7,11 @@
                           implementation of the hot path that IS importable here): ids, weights, hidden_states[-2],
                           pooled / projected outputs
   lcm_known_answers.json  SURVEY.md A.5 closed forms + the 8a-RNG fixture
+  bpe_vocab.json, bpe_merges.txt, bpe_golden.json
+                          a SYNTHETIC CLIP-style byte-level BPE vocabulary (512 byte symbols + merges learned here from the
+                          700 PIE-Bench prompts + the two special tokens; the real 49 408-entry vocabulary is not available
+                          offline) and the ids the installed transformers.CLIPTokenizer produces with it for a list of
+                          prompts (plain, PIE-Bench bracketed, punctuation, digits, contractions, non-ASCII, > 77 tokens)
 """
 import csv
 import json
@@ -73,8 +78,75 @@ def lcm_answers():
         json.dump(kat, f, indent=1)
 
 
+BPE_PROMPTS = [
+    "a photo of a cat", "a [rusty] bicycle leaning on the [red] wall", "", "   two   spaces\tand a tab  ",
+    "it's a dog's life, isn't it? we'll see -- they've won!", "12 monkeys & 3 apples cost $4.50 (approx.)",
+    "caf\u00e9 cr\u00e8me br\u00fbl\u00e9e na\u00efve fa\u00e7ade", "\u00fcber stra\u00dfe \u4e2d\u6587 \u65e5\u672c\u8a9e \u0440\u0443\u0441\u0441\u043a\u0438\u0439",
+    "UPPER case And MiXeD", "<|startoftext|> literal specials <|endoftext|> inside", "e\u0301 combining accent vs \u00e9",
+    "emoji \U0001F600 and symbols \u00a9\u00ae\u2122 ... !!! ???", "x" * 90, " ".join(["word"] * 120),
+    "a_b under_score __ mixed_9 7up", "tabs\nnewlines\r\nand more",
+]
+
+
+def bpe_golden(n_merges=900):
+    """Learn a small byte-level BPE on the PIE-Bench prompts (plain greedy pair counting on the CLIP pre-tokenisation), write
+    vocab.json / merges.txt in CLIP's file formats, then record what transformers.CLIPTokenizer does with them."""
+    import collections
+    import regex
+    from transformers import CLIPTokenizer
+    from fie_amd.tokenizer import _bytes_to_unicode
+    b2u = _bytes_to_unicode()
+    pat = regex.compile(r"'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+")
+    rows = list(csv.DictReader(open(os.path.join(HERE, "pie_bench_items.csv"))))
+    words = collections.Counter()
+    for r in rows:
+        for tok in pat.findall(r["editing_prompt"].lower()):
+            sym = [b2u[b] for b in tok.encode("utf-8")]
+            sym[-1] += "</w>"
+            words[tuple(sym)] += 1
+    merges = []
+    for _ in range(n_merges):
+        pairs = collections.Counter()
+        for w, c in words.items():
+            for a, b in zip(w, w[1:]):
+                pairs[(a, b)] += c
+        if not pairs:
+            break
+        (a, b), cnt = max(pairs.items(), key=lambda kv: (kv[1], kv[0]))
+        if cnt < 2:
+            break
+        merges.append((a, b))
+        new = collections.Counter()
+        for w, c in words.items():
+            out, i = [], 0
+            while i < len(w):
+                if i < len(w) - 1 and w[i] == a and w[i + 1] == b:
+                    out.append(a + b)
+                    i += 2
+                else:
+                    out.append(w[i])
+                    i += 1
+            new[tuple(out)] += c
+        words = new
+    alphabet = [b2u[b] for b in sorted(b2u)]                  # CLIP's vocab order: byte symbols, their </w> forms, merges, specials
+    vocab = {s: i for i, s in enumerate(alphabet + [s + "</w>" for s in alphabet] + [a + b for a, b in merges])}
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    with open(os.path.join(HERE, "bpe_vocab.json"), "w", encoding="utf-8") as f:
+        json.dump(vocab, f, ensure_ascii=False)
+    with open(os.path.join(HERE, "bpe_merges.txt"), "w", encoding="utf-8") as f:
+        f.write("#version: 0.2\n" + "\n".join(f"{a} {b}" for a, b in merges) + "\n")
+    tok = CLIPTokenizer(vocab=vocab, merges=list(merges))
+    prompts = BPE_PROMPTS + [r["editing_prompt"] for r in rows[::35]]
+    ids = tok(prompts, padding="max_length", max_length=77, truncation=True)["input_ids"]
+    with open(os.path.join(HERE, "bpe_golden.json"), "w", encoding="utf-8") as f:
+        json.dump({"transformers": __import__("transformers").__version__, "pad_id": tok.pad_token_id,
+                   "prompts": prompts, "input_ids": ids}, f, ensure_ascii=True)
+
+
 if __name__ == "__main__":
     pie_items()
     clip_golden()
     lcm_answers()
+    bpe_golden()
     print("fixtures written to", HERE)

@@ -292,3 +292,60 @@ def test_forked_graph_budget(rig):
         assert np.abs(outs[0].astype(int) - outs[1].astype(int)).max() <= 8          # guidance differs by 0.01 only
     finally:
         pipe.MAX_FORKED_GRAPHS, pipe.use_graph = old[0], old[2]
+
+
+def test_graph_cache_is_bounded_and_entries_keep_their_own_latents(rig):
+    """ADVICE r1 (pipe.py:41): the hipGraph cache is capped (keys beyond the cap run eagerly, same result), and
+    output_type='latent' returns the latents of the graph that was REPLAYED, not of the most recently captured one."""
+    cfgs, sds32, pipe = rig
+    img = synth_image(23, 128)
+    ctrl = Image.fromarray(np.zeros((128, 128, 3), np.uint8))
+    call = lambda g, ot="np": pipe(prompt="a [toy]", image=img, control_image=ctrl, strength=0.5, guidance_scale=g,
+                                   generator=torch.Generator("cpu").manual_seed(3), output_type=ot).images[0]
+    old = pipe.max_graphs, pipe.use_graph, pipe.eager_overflow
+    try:
+        pipe.use_graph = True
+        lat_a = call(1.71, "latent").clone()           # captures key A
+        lat_b = call(1.95, "latent").clone()           # captures key B (different latents)
+        assert not torch.equal(lat_a, lat_b)
+        assert torch.equal(call(1.71, "latent"), lat_a)           # replay of A returns A's latents although B was captured later
+        assert pipe.last_stats["unet_evals"] == 2
+        pipe.max_graphs = len(pipe._graphs)                      # cache full from here on
+        n = len(pipe._graphs)
+        eager = call(1.83)
+        assert len(pipe._graphs) == n and pipe.eager_overflow == old[2] + 1
+        pipe.max_graphs = n + 1
+        graphed = call(1.83)
+        assert len(pipe._graphs) == n + 1 and np.array_equal(eager, graphed)
+    finally:
+        pipe.max_graphs, pipe.use_graph = old[0], old[1]
+
+
+def test_editor_from_a_weights_directory_whose_topology_matches_no_preset(fie, tmp_path):
+    """FastEditor(weights_dir=...) builds its graphs from the directory's config.json files (default ctor flags: ssd-1b would
+    otherwise pick the guessed 'small' ControlNet preset) and matches the oracle run on the same files."""
+    from test_oracle_cpu import _write_stack
+    from fie_amd import stack, weights
+    from oracle import canny, metrics, pipeline as opipe
+    from src.pipeline import FastEditor
+    base = stack.stack_configs("tiny", True)
+    unet = dict(base["unet"], name="odd-unet", down_attn=((0, 0), (1, 2), (2, 1)), mid_attn=0, mid_resnets=1,
+                up_attn=((1, 2, 1), (2, 1, 1), (0, 0, 0)))
+    cn = dict(base["controlnet"], name="odd-cn", down_attn=((0, 0), (0, 0), (1, 1)), mid_attn=1,
+              conditioning_embedding_out_channels=(8, 16, 24, 40))
+    cfgs = dict(base, unet=unet, controlnet=cn, clip_g=dict(base["clip_g"], eos_token_id=2))
+    sds = {k: weights.synth_state_dict(cfgs[k], seed=90 + i, dtype=torch.float16) for i, k in enumerate(stack.KEYS)}
+    _write_stack(str(tmp_path), cfgs, sds)
+    ed = FastEditor(model_name="ssd-1b", enable_cpu_offload=False, weights_dir=str(tmp_path), noise_dtype=torch.float32)
+    assert ed.presets["unet"] == "unet/config.json" and ed.pipe.cfgs["unet"]["up_attn"] == unet["up_attn"]
+    assert ed.pipe.cfgs["controlnet"]["conditioning_embedding_out_channels"] == (8, 16, 24, 40)
+    img = synth_image(13, 128)
+    ctrl = Image.fromarray(canny.canny_rgb(np.asarray(img)))
+    pipe = ed.pipe
+    prompt = "a [red] circle"
+    out = pipe(prompt=prompt, negative_prompt="", image=img, control_image=ctrl, strength=0.8, num_inference_steps=4,
+               guidance_scale=1.5, controlnet_conditioning_scale=0.5, generator=torch.Generator("cpu").manual_seed(42)).images[0]
+    sds32 = {k: {n: v.float() for n, v in sd.items()} for k, sd in sds.items()}
+    ref = opipe.run(sds32, pipe.cfgs, img, ctrl, _ids(pipe, [prompt]), _ids(pipe, [""]), strength=0.8, num_inference_steps=4,
+                    guidance_scale=1.5, controlnet_conditioning_scale=0.5, generator=torch.Generator("cpu").manual_seed(42))
+    assert metrics.ssim(out, ref, size=None) >= 0.99
