@@ -3,6 +3,9 @@
 #include <string.h>
 #include "fie_internal.h"
 
+int fie_gemm_init(void);
+int fie_gemm8_init(void);
+
 static thread_local char g_err[512] = "";
 
 void fie_set_error(const char* fmt, ...) {
@@ -35,6 +38,17 @@ int fie_ctx_create(int device, void* stream, fie_ctx** out) {
                       prop.gcnArchName);
         return FIE_ENODEV;
     }
+    // per-device kernel attributes (dynamic LDS sizes) are set here, once, not on the launch path
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (hipSetDevice(device) != hipSuccess) {
+        fie_set_error("fie_ctx_create: hipSetDevice(%d) failed", device);
+        return FIE_EHIP;
+    }
+    int rc = fie_gemm_init();
+    if (rc == FIE_OK) rc = fie_gemm8_init();
+    (void)hipSetDevice(cur);
+    if (rc != FIE_OK) return rc;
     fie_ctx* c = new fie_ctx();
     c->device = device;
     c->stream = (hipStream_t)stream;

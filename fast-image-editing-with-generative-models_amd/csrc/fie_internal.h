@@ -13,10 +13,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+struct fie_tile_override { int mode, M, N, K, code; };   // tuning hook: per-shape GEMM / conv tile code (mode 0 GEMM, 1 conv)
+
 struct fie_ctx {
     int device;
     hipStream_t stream;
     int num_cus;
+    // tuning / test hooks of the GEMM launch table (fie_debug_*): per ctx, never process-global
+    int force_tile = 0;
+    int n_overrides = 0;
+    fie_tile_override overrides[32];
+    char last_kernel[96] = "";
 };
 
 void fie_set_error(const char* fmt, ...);

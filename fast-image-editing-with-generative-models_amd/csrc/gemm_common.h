@@ -1,0 +1,122 @@
+// Shared pieces of the fp16 GEMM / 3x3 implicit-GEMM convolution kernels (gemm_conv.hip: register-staged fallback + LDS-DMA
+// ring kernels; gemm8.hip: the 256x256 phased kernel).  One problem description serves both entries of include/fie.h
+// (fie_gemm_f16, fie_conv3x3_nhwc_f16):
+//   C[M,N] = epi(A[M,K] * W[N,K]^T), "A" = a row-major matrix (optionally the column concatenation of two matrices) or the
+//   on-the-fly im2col view of an NHWC tensor (3x3 taps, stride 1/2, symmetric or VAE-style asymmetric padding, optional fused
+//   nearest-2x upsample).
+// MFMA operands are "swapped": the weight fragment is the A operand and the activation fragment the B operand of
+// v_mfma_f32_16x16x32_f16, so a lane owns 4 CONSECUTIVE output channels of one output row (8-byte bias / residual loads and
+// stores; GEGLU value / gate pairs in one lane).  LDS images are rows of 128 B (one 64-deep K-step), 16-byte chunks
+// XOR-swizzled by (row & 7): applied on the SOURCE offset of the LDS-DMA and again on the ds_read_b128 fragment reads.
+#pragma once
+#include "fie_internal.h"
+
+namespace fie_gemm {
+
+constexpr int BK = 64;
+
+struct GemmArgs {
+    const half_t* A1; int64_t lda1; int K1;
+    const half_t* A2; int64_t lda2;
+    // conv view of A1
+    int H, W, Cin, OH, OW, stride, pt, pl, ups;
+    const half_t* Wt; int64_t ldw;
+    half_t* C; int64_t ldc;
+    int M, N, K;
+    const half_t* bias;
+    const half_t* rowbias; int64_t ld_rowbias; int rows_per_batch;
+    const half_t* res; int64_t ldr;
+    float scale; int act;
+    int nbm, nbn;
+    int64_t a1_bytes, a2_bytes, w_bytes;   // operand extents for the v3 buffer descriptors
+    int order;                              // 0: n-tiles fastest (an XCD owns a range of rows), 1: m-tiles fastest (an XCD owns a range of columns)
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
+
+template <int FM, int FN, int WM, int WN>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    // ---- epilogue: lane holds C[m = .. + fr][n = .. + fq*4 + (0..3)]
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = m0 + wm * WM + j * 16 + fr;
+        if (m >= p.M) continue;
+        const half_t* rb = nullptr;
+        if (p.rowbias) rb = p.rowbias + (int64_t)(m / p.rows_per_batch) * p.ld_rowbias;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int n = n0 + wn * WN + i * 16 + fq * 4;
+            if (n >= p.N) continue;
+            f32x4 v = acc[i][j];
+            if (p.bias) {
+                const f16x4 b = *reinterpret_cast<const f16x4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+            }
+            if (rb) {
+                const f16x4 b = *reinterpret_cast<const f16x4*>(rb + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+            }
+            if (p.act == FIE_ACT_GEGLU) {
+                f16x2 o;
+                o[0] = (half_t)(v[0] * fie_gelu(v[1]) * p.scale);
+                o[1] = (half_t)(v[2] * fie_gelu(v[3]) * p.scale);
+                *reinterpret_cast<f16x2*>(p.C + (int64_t)m * p.ldc + (n >> 1)) = o;
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = v[r];
+                if (p.act == FIE_ACT_SILU) x = fie_silu(x);
+                else if (p.act == FIE_ACT_GELU) x = fie_gelu(x);
+                else if (p.act == FIE_ACT_QUICK_GELU) x = fie_qgelu(x);
+                v[r] = x * p.scale;
+            }
+            if (p.res) {
+                const f16x4 b = *reinterpret_cast<const f16x4*>(p.res + (int64_t)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+            }
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+            *reinterpret_cast<f16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+        }
+    }
+}
+
+// ---- LDS-DMA helpers (buffer_load_dwordx4 ... offen lds): a wave-uniform descriptor + a per-lane 32-bit byte offset; lanes
+// whose offset is >= num_records (im2col padding, rows >= M, the K tail: kOob) read zeros through the descriptor's range check.
+constexpr unsigned kOob = 0x80000000u;
+
+__device__ __forceinline__ void bload16(__amdgpu_buffer_rsrc_t rsrc, half_t* lds_dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// XCD-aware bijective tile remap: consecutive tile ids run on one XCD (blocks b and b + 8 share an XCD's L2)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+}  // namespace fie_gemm
+
+// gemm8.hip: the 256x256 phased kernel.  conv != 0: im2col view with Cin % 64 == 0.  Shapes must satisfy the LDS-DMA
+// eligibility rule of gemm_conv.hip (operands < 2 GiB, K1 == K or K1 % 64 == 0).
+int fie_launch_gemm8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int conv);
+int fie_gemm8_init(void);          // per-device function attributes (dynamic LDS size); called from fie_ctx_create
+int fie_gemm_init(void);           // same for the kernels of gemm_conv.hip

@@ -53,12 +53,11 @@ SIGNATURES = {
     "fie_canny_workspace_bytes": [_I, _I],
     "fie_canny_rgb_device_u8": [_P, _P, _I, _I, _I, _I, _P, _P, _c.POINTER(_I)],
     "fie_resize_rgb_u8": [_P, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P],
-    "fie_debug_force_tile": [_I],
+    "fie_debug_force_tile": [_P, _I],
     "fie_debug_attn_variant": [_I],
     "fie_debug_gn_onepass": [_I],
-    "fie_debug_extra_lds": [_I],
-    "fie_debug_tile_override": [_c.c_char_p],
-    "fie_debug_last_gemm_kernel": [],
+    "fie_debug_tile_override": [_P, _c.c_char_p],
+    "fie_debug_last_gemm_kernel": [_P],
 }
 
 _lib = None
@@ -91,9 +90,10 @@ def lib():
     return _lib
 
 
-def last_gemm_kernel():
-    """Kernel / tile the last GEMM or conv launch of this thread used (names the roofline kernel in bench.py)."""
-    return lib().fie_debug_last_gemm_kernel().decode()
+def last_gemm_kernel(ctx=None):
+    """Kernel / tile the last GEMM or conv launch of `ctx` used (names the roofline kernel in bench.py)."""
+    ctx = ctx or context(torch.cuda.current_device())
+    return lib().fie_debug_last_gemm_kernel(ctx.h).decode()
 
 
 class FieError(RuntimeError):
@@ -133,6 +133,15 @@ class Context:
         if s != self._stream:
             _chk(lib().fie_ctx_set_stream(self.h, s))
             self._stream = s
+
+    # ------------------------------------------------------------------ tuning / test hooks (per ctx)
+    def force_tile(self, code):
+        """0 = heuristic; see include/fie.h for the codes.  An ineligible code makes the op raise FieError."""
+        _chk(lib().fie_debug_force_tile(self.h, int(code)))
+
+    def tile_override(self, spec):
+        """"mode,M,N,K=code;..." per-shape tile codes (None clears).  Returns the number of entries parsed."""
+        return lib().fie_debug_tile_override(self.h, spec.encode() if spec else None)
 
     def close(self):
         if self.h:

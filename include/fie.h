@@ -165,13 +165,14 @@ int fie_lcm_step_f32(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, floa
                      float sqrt_ab_prev, float sqrt_1mab_prev, void* model_in, int copies, float inv_scaling,
                      void* decode_in);
 
-/* ---- tuning hook for micro-benchmarks: force the GEMM/conv tile (0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64).
- * Process-global; not part of the drop-in surface. */
-int fie_debug_force_tile(int tile);
+/* ---- tuning / test hooks (not part of the drop-in surface).  Tile hooks are PER CTX: nothing process-global sits on the
+ * launch path.  Tile codes: 1/2/3 register-staged 128x128 / 128x64 / 64x64 (any shape); 41/42/43 LDS-DMA ring 128x128 /
+ * 128x64 / 64x64; 51 ring 128x128 x 8 waves; 61/62 ring 256x256 / 256x128 x 8 waves; 81 phased 256x256 (gemm8.hip).
+ * + 2000: m-tiles fastest tile order.  A code the shape is not eligible for returns FIE_EINVAL from the op. */
+int fie_debug_force_tile(fie_ctx* ctx, int tile);                  /* 0 = heuristic */
+int fie_debug_tile_override(fie_ctx* ctx, const char* spec);       /* "mode,M,N,K=code;..." (mode 0 GEMM, 1 conv); NULL clears; returns the count */
+const char* fie_debug_last_gemm_kernel(fie_ctx* ctx);              /* kernel / tile of the last fie_gemm_f16 / fie_conv3x3_nhwc_f16 launch */
 int fie_debug_attn_variant(int variant);   /* 0 = default kernel, 1 = first-generation kernel (A/B benchmarking) */
-int fie_debug_tile_override(const char* spec); /* "mode,M,N,K=code;..." per-shape tile codes (whole-pipeline A/B); NULL clears; returns the count */
-int fie_debug_extra_lds(int bytes);        /* pad the v3 GEMM/conv kernels' dynamic LDS (occupancy A/B probe); 0 = off */
-const char* fie_debug_last_gemm_kernel(void); /* name / tile of the last fie_gemm_f16 / fie_conv3x3_nhwc_f16 launch of this thread */
 int fie_debug_gn_onepass(int enable);      /* 1 = default (single-pass GroupNorm on small maps), 0 = always partial/finalize/apply */
 
 /* ---- K11 Canny on the host (integer exact).  Replaces cv2.cvtColor(RGB2GRAY) + cv2.Canny at

@@ -14,6 +14,7 @@ from src.pipeline import FastEditor  # noqa: E402
 specs = sys.argv[1:] or [""]
 ed = FastEditor(model_name="ssd-1b", use_full_controlnet=True, enable_cpu_offload=False)
 pipe = ed.pipe
+ctx = pipe.ctx
 pipe.fork_streams = False      # single-stream graphs: immune to the hardware-queue collisions that many forked graphs in one process cause
 img = synth_item_image(3).resize((1024, 1024))
 ctrl = ed.preprocess_image(img)
@@ -22,7 +23,7 @@ ctrl = ed.preprocess_image(img)
 n_cap = 0
 for rnd in range(3):
     for sp in specs:
-        hip.lib().fie_debug_tile_override(sp.encode() if sp else None)
+        ctx.tile_override(sp or None)
         job = pipe.prepare("a photo of a [red] house", "", img, ctrl, 0.5, 4, 1.5 + 1e-4 * n_cap, 0.5, torch.Generator().manual_seed(42))
         n_cap += 1
         pipe.run_device_graphed(job)
@@ -35,4 +36,4 @@ for rnd in range(3):
         torch.cuda.synchronize()
         fwd = time_unet_forward(pipe, job, iters=4)
         print(f"round {rnd} [{sp or 'default'}]: edit {e0.elapsed_time(e1) / 8:.2f} ms, unet fwd {fwd:.2f} ms", flush=True)
-hip.lib().fie_debug_tile_override(None)
+ctx.tile_override(None)

@@ -23,7 +23,7 @@ if kind == "gemm":
         w = ctx.pack_linear(torch.randn(n, k, device="cuda", dtype=torch.float16) * k ** -0.5, geglu=True)
         bias = torch.randn(n, device="cuda", dtype=torch.float16)
         out = torch.empty(m, n // 2, device="cuda", dtype=torch.float16)
-    hip.lib().fie_debug_force_tile(code)
+    ctx.force_tile(code)
     for _ in range(iters):
         if geglu:
             ctx.gemm(a, w, n, out=out, bias=bias, act=hip.ACT_GEGLU)
@@ -34,7 +34,7 @@ else:
     iters = int(sys.argv[8]) if len(sys.argv) > 8 else 5
     x = torch.randn(b, h, w_, cin, device="cuda", dtype=torch.float16)
     wt = ctx.pack_conv3x3(torch.randn(cout, cin, 3, 3, device="cuda", dtype=torch.float16) * (9 * cin) ** -0.5)
-    hip.lib().fie_debug_force_tile(code)
+    ctx.force_tile(code)
     for _ in range(iters):
         ctx.conv3x3(x, wt, cout)
 torch.cuda.synchronize()

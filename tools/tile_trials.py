@@ -27,6 +27,7 @@ TRIALS = {
 
 ed = FastEditor(model_name="ssd-1b", use_full_controlnet=True, enable_cpu_offload=False)
 pipe = ed.pipe
+ctx = pipe.ctx
 img = synth_item_image(3).resize((1024, 1024))
 ctrl = ed.preprocess_image(img)
 job = pipe.prepare("a photo of a [red] house", "", img, ctrl, 0.5, 4, 1.5, 0.5, torch.Generator().manual_seed(42))
@@ -35,7 +36,7 @@ torch.cuda.synchronize()
 
 
 def measure(spec):
-    hip.lib().fie_debug_tile_override(spec.encode() if spec else None)
+    ctx.tile_override(spec or None)
     return min(time_unet_forward(pipe, job, iters=4) for _ in range(2))
 
 
@@ -54,4 +55,4 @@ else:
             t = measure(f"{shape}={c}")
             row.append(f"{c}: {(t / base - 1) * 100:+.2f}%")
         print("  ".join(row), flush=True)
-hip.lib().fie_debug_tile_override(None)
+ctx.tile_override(None)
