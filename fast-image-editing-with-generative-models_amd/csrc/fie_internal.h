@@ -21,6 +21,7 @@ struct fie_ctx {
     int num_cus;
     // tuning / test hooks of the GEMM launch table (fie_debug_*): per ctx, never process-global
     int force_tile = 0;
+    int gemm_probe = 0;
     int n_overrides = 0;
     fie_tile_override overrides[32];
     char last_kernel[96] = "";

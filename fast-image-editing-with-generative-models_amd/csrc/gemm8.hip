@@ -35,7 +35,7 @@ namespace {
 
 constexpr int BUFH = 512 * BK;      // halfs per K-tile buffer: activation rows 0-255, weight rows 256-511
 
-template <int MODE>    // 0 = GEMM (A = [A1 | A2]), 2 = conv with Cin % 64 == 0
+template <int MODE, int SPLIT>    // MODE 0 = GEMM (A = [A1 | A2]), 2 = conv with Cin % 64 == 0; SPLIT: second DMA piece inside the MFMA cluster
 __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) half_t smem[];
 
@@ -50,9 +50,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     const int lr = lane >> 3;
     const int c8 = (lane & 7) ^ lr;
 
-    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)p.a1_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, (int)p.a2_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, (int)p.w_bytes, 0x00020000);
+    const int live = p.probe == 1 ? 0 : 1;                           // probe 1: zero-record descriptors drop every load
+    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)p.a1_bytes * live, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, (int)p.a2_bytes * live, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, (int)p.w_bytes * live, 0x00020000);
+    const int lm0 = p.probe == 2 ? 0 : m0, ln0 = p.probe == 2 ? 0 : n0;   // probe 2: all tiles load tile (0,0)
 
     // ---- DMA pieces (8 rows x 128 B per wave-instruction).  A half-tile has 16 pieces; this wave issues pieces `wave` and
     // `wave + 8`.  Tile row of piece i:  weights (i >> 2) * 64 + (i & 3) * 8 (+ 32 for W1);  activations i * 8 (+ 64 for A1).
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            w_off[s][j] = (unsigned)(n0 + wrow0 + 128 * j + 32 * s + lr) * (unsigned)p.ldw * 2u + c8 * 16u;
+            w_off[s][j] = (unsigned)(ln0 + wrow0 + 128 * j + 32 * s + lr) * (unsigned)p.ldw * 2u + c8 * 16u;
     unsigned a_off[2][2], a_off2[2][2];                             // GEMM: offsets into A1 / A2; conv: offsets of the current tap
     int a_ih[2][2], a_iw[2][2];
     unsigned a_img[2][2];
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m = m0 + arow0 + 128 * j + 64 * s + lr;
+            const int m = lm0 + arow0 + 128 * j + 64 * s + lr;
             a_ok[s][j] = m < p.M;
             if (MODE == 2) {
                 const int hw = p.OH * p.OW;
@@ -96,48 +98,49 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     const int nk = (p.K + BK - 1) / BK;
     const bool ktail = (p.K % BK) != 0;
 
-    auto issue_w = [&](auto setc, int kt, int buf) {
-        constexpr int S = decltype(setc)::value;
+    // One half-tile = two DMA pieces per wave (J = 0, 1).  Every index below is a compile-time constant: a runtime-indexed
+    // offset array would live in scratch, and its reload's vmcnt(0) would drain the DMA pipeline in every phase.
+    // SPLIT: piece 0 goes out in the phase's load segment, piece 1 from inside the MFMA cluster.
+    unsigned so_a[2] = {0, 0};                                       // conv: scalar K offset of the half-tile being issued, per set
+    auto fire_w = [&](auto setc, auto piecec, int kt, int buf) {
+        constexpr int S = decltype(setc)::value, J = decltype(piecec)::value;
         if (kt >= nk) return;
-        half_t* dst = smem + buf * BUFH + (256 + wrow0 + 32 * S) * BK;
-        const unsigned so = (unsigned)kt * (BK * 2);
-        bload16(rs_w, dst, w_off[S][0], so);
-        bload16(rs_w, dst + 128 * BK, w_off[S][1], so);
+        bload16(rs_w, smem + buf * BUFH + (256 + wrow0 + 32 * S + 128 * J) * BK, w_off[S][J], (unsigned)kt * (BK * 2));
     };
-    auto issue_a = [&](auto setc, int kt, int buf) {
+    auto prep_a = [&](auto setc, int kt) {                           // conv: (re)compute the tap's offsets, advance (channel step, tap)
         constexpr int S = decltype(setc)::value;
-        if (kt >= nk) return;
-        half_t* dst = smem + buf * BUFH + (arow0 + 64 * S) * BK;
-        if (MODE == 2) {
-            if (cs[S] == 0) {
-                const int ky = (ftap[S] * 11) >> 5, kx = ftap[S] - 3 * ky;
-                const int hlim = p.H << p.ups, wlim = p.W << p.ups;
+        if (MODE != 2 || kt >= nk) return;
+        if (cs[S] == 0) {
+            const int ky = (ftap[S] * 11) >> 5, kx = ftap[S] - 3 * ky;
+            const int hlim = p.H << p.ups, wlim = p.W << p.ups;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int ih = a_ih[S][j] + ky, iw = a_iw[S][j] + kx;
-                    const bool ok = a_ok[S][j] && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
-                    a_off[S][j] = ok ? a_img[S][j] + (unsigned)((ih >> p.ups) * p.W + (iw >> p.ups)) * (unsigned)p.Cin * 2u + c8 * 16u : kOob;
-                }
+            for (int j = 0; j < 2; ++j) {
+                const int ih = a_ih[S][j] + ky, iw = a_iw[S][j] + kx;
+                const bool ok = a_ok[S][j] && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+                a_off[S][j] = ok ? a_img[S][j] + (unsigned)((ih >> p.ups) * p.W + (iw >> p.ups)) * (unsigned)p.Cin * 2u + c8 * 16u : kOob;
             }
-            const unsigned so = (unsigned)cs[S] * (BK * 2);
-            bload16(rs_a1, dst, a_off[S][0], so);
-            bload16(rs_a1, dst + 128 * BK, a_off[S][1], so);
-            if (++cs[S] == csteps) { cs[S] = 0; ++ftap[S]; }
+        }
+        so_a[S] = (unsigned)cs[S] * (BK * 2);
+        if (++cs[S] == csteps) { cs[S] = 0; ++ftap[S]; }
+    };
+    auto fire_a = [&](auto setc, auto piecec, int kt, int buf) {
+        constexpr int S = decltype(setc)::value, J = decltype(piecec)::value;
+        if (kt >= nk) return;
+        half_t* dst = smem + buf * BUFH + (arow0 + 64 * S + 128 * J) * BK;
+        if (MODE == 2) {
+            bload16(rs_a1, dst, a_off[S][J], so_a[S]);
         } else if (ktail && kt == nk - 1) {                           // last, partial K-tile: columns >= K read as zero
-            const bool in_k = kt * BK + c8 * 8 < p.K;
-            const unsigned so = (unsigned)kt * (BK * 2);
-            bload16(rs_a1, dst, in_k ? a_off[S][0] : kOob, so);
-            bload16(rs_a1, dst + 128 * BK, in_k ? a_off[S][1] : kOob, so);
+            bload16(rs_a1, dst, kt * BK + c8 * 8 < p.K ? a_off[S][J] : kOob, (unsigned)kt * (BK * 2));
         } else if (kt < k1_steps || k1_steps == 0) {
-            const unsigned so = (unsigned)kt * (BK * 2);
-            bload16(rs_a1, dst, a_off[S][0], so);
-            bload16(rs_a1, dst + 128 * BK, a_off[S][1], so);
+            bload16(rs_a1, dst, a_off[S][J], (unsigned)kt * (BK * 2));
         } else {
-            const unsigned so = (unsigned)(kt - k1_steps) * (BK * 2);
-            bload16(rs_a2, dst, a_off2[S][0], so);
-            bload16(rs_a2, dst + 128 * BK, a_off2[S][1], so);
+            bload16(rs_a2, dst, a_off2[S][J], (unsigned)(kt - k1_steps) * (BK * 2));
         }
     };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    auto issue_w = [&](auto setc, int kt, int buf) { fire_w(setc, P0{}, kt, buf); fire_w(setc, P1{}, kt, buf); };
+    auto issue_a = [&](auto setc, int kt, int buf) { prep_a(setc, kt); fire_a(setc, P0{}, kt, buf); fire_a(setc, P1{}, kt, buf); };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 
@@ -161,6 +164,25 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
 
     f16x8 fa[4][2], fw0[2][2], fw1[2][2];
 
+    // 16 MFMAs of one quadrant: channel tiles ci0, ci0 + 1 (fragments fw) x row tiles rj0 .. rj0 + 3 (fragments fa); with SPLIT
+    // the half-tile's second DMA piece is issued behind the first four MFMAs
+#define FIE_QUADRANT(FW, CI0, RJ0, LATE)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
+            acc[CI0 + i][RJ0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FW[i][0], fa[j][0], acc[CI0 + i][RJ0 + j], 0, 0, 0); \
+            acc[CI0 + i][RJ0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FW[i][1], fa[j][1], acc[CI0 + i][RJ0 + j], 0, 0, 0); \
+            if (SPLIT && i == 0 && j == 1) {                                                                               \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+                LATE;                                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+            }                                                                                                              \
+        }                                                                                                                  \
+    }                                                                                                                      \
+    __builtin_amdgcn_s_setprio(0);                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+
     auto ktile = [&](auto bufc, int t) {
         constexpr int BUF = decltype(bufc)::value;
         const half_t* sa = smem + BUF * BUFH + a_base;
@@ -176,20 +198,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
             fa[j][0] = *reinterpret_cast<const f16x8*>(sa + j * 16 * BK + frag0);
             fa[j][1] = *reinterpret_cast<const f16x8*>(sa + j * 16 * BK + frag1);
         }
-        issue_a(S1{}, t + 1, BUF ^ 1);
+        prep_a(S1{}, t + 1);
+        fire_a(S1{}, P0{}, t + 1, BUF ^ 1);
+        if (!SPLIT) fire_a(S1{}, P1{}, t + 1, BUF ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw0[i][0], fa[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw0[i][1], fa[j][1], acc[i][j], 0, 0, 0);
-            }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+        FIE_QUADRANT(fw0, 0, 0, fire_a(S1{}, P1{}, t + 1, BUF ^ 1))
         __builtin_amdgcn_s_barrier();
         // ------------------------------------------------------------------ phase 2: quadrant (a0, w1)
 #pragma unroll
@@ -197,20 +211,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
             fw1[i][0] = *reinterpret_cast<const f16x8*>(sw + (32 + i * 16) * BK + frag0);
             fw1[i][1] = *reinterpret_cast<const f16x8*>(sw + (32 + i * 16) * BK + frag1);
         }
-        issue_w(S0{}, t + 2, BUF);
+        fire_w(S0{}, P0{}, t + 2, BUF);
+        if (!SPLIT) fire_w(S0{}, P1{}, t + 2, BUF);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw1[i][0], fa[j][0], acc[2 + i][j], 0, 0, 0);
-                acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw1[i][1], fa[j][1], acc[2 + i][j], 0, 0, 0);
-            }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+        FIE_QUADRANT(fw1, 2, 0, fire_w(S0{}, P1{}, t + 2, BUF))
         __builtin_amdgcn_s_barrier();
         // ------------------------------------------------------------------ phase 3: quadrant (a1, w1)
 #pragma unroll
@@ -218,39 +223,24 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
             fa[j][0] = *reinterpret_cast<const f16x8*>(sa + (64 + j * 16) * BK + frag0);
             fa[j][1] = *reinterpret_cast<const f16x8*>(sa + (64 + j * 16) * BK + frag1);
         }
-        issue_a(S0{}, t + 2, BUF);
+        prep_a(S0{}, t + 2);
+        fire_a(S0{}, P0{}, t + 2, BUF);
+        if (!SPLIT) fire_a(S0{}, P1{}, t + 2, BUF);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw1[i][0], fa[j][0], acc[2 + i][4 + j], 0, 0, 0);
-                acc[2 + i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw1[i][1], fa[j][1], acc[2 + i][4 + j], 0, 0, 0);
-            }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+        FIE_QUADRANT(fw1, 2, 4, fire_a(S0{}, P1{}, t + 2, BUF))
         __builtin_amdgcn_s_barrier();
         // ------------------------------------------------------------------ phase 4: quadrant (a1, w0), w0 still in registers
-        issue_w(S1{}, t + 2, BUF);
-        // K-tile t+1 (read from the next phase on) must have landed: only W0, A0, W1 of K-tile t+2 may still be in flight
-        if (t + 2 < nk) wait_vm<6>(); else wait_vm<0>();
+        fire_w(S1{}, P0{}, t + 2, BUF);
+        if (!SPLIT) fire_w(S1{}, P1{}, t + 2, BUF);
+        // K-tile t+1 (read from the next phase on) must have landed: only W0, A0 and the pieces of W1 of K-tile t+2 issued so far
+        // may still be in flight (3 half-tiles x 2 pieces; with SPLIT this phase's second piece is not out yet: 5)
+        if (t + 2 < nk) wait_vm<SPLIT ? 5 : 6>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw0[i][0], fa[j][0], acc[i][4 + j], 0, 0, 0);
-                acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw0[i][1], fa[j][1], acc[i][4 + j], 0, 0, 0);
-            }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+        FIE_QUADRANT(fw0, 0, 4, fire_w(S1{}, P1{}, t + 2, BUF))
         __builtin_amdgcn_s_barrier();
     };
+#undef FIE_QUADRANT
 
     for (int t = 0; t < nk; t += 2) {
         ktile(S0{}, t);
@@ -266,9 +256,10 @@ constexpr int kLds8 = 2 * BUFH * (int)sizeof(half_t);               // 128 KiB
 }  // namespace
 
 int fie_gemm8_init(void) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
+    hipError_t e = hipSuccess;
+    for (const void* f : {reinterpret_cast<const void*>(&gemm8_kernel<0, 1>), reinterpret_cast<const void*>(&gemm8_kernel<2, 1>),
+                          reinterpret_cast<const void*>(&gemm8_kernel<0, 0>), reinterpret_cast<const void*>(&gemm8_kernel<2, 0>)})
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8);
     if (e != hipSuccess) {
         fie_set_error("gemm8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return FIE_EHIP;
@@ -276,10 +267,12 @@ int fie_gemm8_init(void) {
     return FIE_OK;
 }
 
-int fie_launch_gemm8(fie_ctx* ctx, const GemmArgs& a, int conv) {
+int fie_launch_gemm8(fie_ctx* ctx, const GemmArgs& a, int conv, int split) {
     const dim3 grid((unsigned)(a.nbm * a.nbn));
-    if (conv) hipLaunchKernelGGL((gemm8_kernel<2>), grid, dim3(512), kLds8, ctx->stream, a);
-    else hipLaunchKernelGGL((gemm8_kernel<0>), grid, dim3(512), kLds8, ctx->stream, a);
+    if (conv && split) hipLaunchKernelGGL((gemm8_kernel<2, 1>), grid, dim3(512), kLds8, ctx->stream, a);
+    else if (conv) hipLaunchKernelGGL((gemm8_kernel<2, 0>), grid, dim3(512), kLds8, ctx->stream, a);
+    else if (split) hipLaunchKernelGGL((gemm8_kernel<0, 1>), grid, dim3(512), kLds8, ctx->stream, a);
+    else hipLaunchKernelGGL((gemm8_kernel<0, 0>), grid, dim3(512), kLds8, ctx->stream, a);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

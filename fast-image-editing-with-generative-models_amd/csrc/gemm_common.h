@@ -29,6 +29,7 @@ struct GemmArgs {
     float scale; int act;
     int nbm, nbn;
     int64_t a1_bytes, a2_bytes, w_bytes;   // operand extents for the v3 buffer descriptors
+    int probe;                              // timing-only probes (fie_debug_gemm_probe; outputs are wrong): 1 = every DMA load dropped (zero-record descriptors), 2 = every tile fetches tile (0,0)'s operands (all L2 hits)
     int order;                              // 0: n-tiles fastest (an XCD owns a range of rows), 1: m-tiles fastest (an XCD owns a range of columns)
 };
 
@@ -117,6 +118,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // gemm8.hip: the 256x256 phased kernel.  conv != 0: im2col view with Cin % 64 == 0.  Shapes must satisfy the LDS-DMA
 // eligibility rule of gemm_conv.hip (operands < 2 GiB, K1 == K or K1 % 64 == 0).
-int fie_launch_gemm8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int conv);
+int fie_launch_gemm8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int conv, int split);
 int fie_gemm8_init(void);          // per-device function attributes (dynamic LDS size); called from fie_ctx_create
 int fie_gemm_init(void);           // same for the kernels of gemm_conv.hip

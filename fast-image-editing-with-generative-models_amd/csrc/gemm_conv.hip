@@ -173,9 +173,11 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     const int lr = lane >> 3;
     const int c8 = (lane & 7) ^ lr;
 
-    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)p.a1_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, (int)p.a2_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, (int)p.w_bytes, 0x00020000);
+    const int live = p.probe == 1 ? 0 : 1;                 // timing probes, see GemmArgs::probe
+    const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)p.a1_bytes * live, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, (int)p.a2_bytes * live, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, (int)p.w_bytes * live, 0x00020000);
+    const int lm0 = p.probe == 2 ? 0 : m0, ln0 = p.probe == 2 ? 0 : n0;
 
     // per-lane byte offsets
     unsigned a_off1[RA], a_off2[RA];       // GEMM: row offsets into A1 / A2;  conv: a_off1 = offset for the current tap
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     bool a_ok[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + (wave + NW * i) * 8 + lr;
+        const int m = lm0 + (wave + NW * i) * 8 + lr;
         a_ok[i] = m < p.M;
         if (MODE == 2) {
             const int hw = p.OH * p.OW;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     }
     unsigned w_off[RW];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) w_off[i] = (unsigned)(n0 + (wave + NW * i) * 8 + lr) * (unsigned)p.ldw * 2u + c8 * 16u;
+    for (int i = 0; i < RW; ++i) w_off[i] = (unsigned)(ln0 + (wave + NW * i) * 8 + lr) * (unsigned)p.ldw * 2u + c8 * 16u;
 
     int cs = 0, ftap = 0;
     const int csteps = MODE == 2 ? p.Cin / BK : 1;
@@ -320,10 +322,10 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
 //   41 / 42 / 43   gemm3_kernel  128x128 / 128x64 / 64x64, 3 stages, 4 waves
 //   51             gemm3_kernel  128x128, 3 stages, 8 waves
 //   61 / 62        gemm3_kernel  256x256 x 2 stages / 256x128 x 3 stages, 8 waves
-//   81             gemm8_kernel  256x256 phased
+//   81 / 82        gemm8_kernel  256x256 phased (82: second DMA piece of each phase inside the MFMA cluster, A/B: slower)
 struct TileDim { int code, bm, bn; };
 constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {41, 128, 128}, {42, 128, 64}, {43, 64, 64},
-                              {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}};
+                              {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256}};
 
 template <int MODE>
 int launch(fie_ctx* ctx, GemmArgs& a) {
@@ -332,24 +334,29 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     // LDS-DMA kernels (codes >= 40): 32-bit buffer offsets (operands < 2 GiB) and K-steps that never straddle a 3x3 tap / the A1|A2 seam
     const bool dma_ok = a.a1_bytes < (1ll << 31) && a.a2_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) &&
                         (MODE == 1 ? a.Cin % BK == 0 : (a.K1 == a.K || a.K1 % BK == 0));
-    // Selection (tools/microbench.py per op + tools/tile_trials.py inside the UNet, profiles/r02_microbench.md).  The K loop is
-    // paced by the per-CU global->LDS path, so a tile's FLOP per staged byte BM*BN/(BM+BN) decides its ceiling: the largest
-    // tile that still fills the chip wins; 256x256 runs the phased kernel.
-    const int64_t b256 = blocks(256, 256), b62 = blocks(256, 128);
+    // Selection: tools/tile_table.py (interleaved rounds per shape, profiles/r02_tile_table.md) + tools/tile_trials.py inside the
+    // UNet.  The K loop is paced by the per-CU global->LDS issue path (~100 cycles per 1 KiB piece), so a tile's FLOP per
+    // staged byte BM*BN/(BM+BN) decides its ceiling -- but only while the grid still fills the CUs: the largest tile that does wins.
+    const int64_t b256 = blocks(256, 256), b62 = blocks(256, 128), b51 = blocks(128, 128), b42 = blocks(128, 64);
     int code;
     if (!dma_ok) {
-        code = blocks(128, 64) >= cus ? 2 : 3;
+        code = b42 >= cus ? 2 : 3;
     } else if (MODE == 1) {
-        if (a.N % 256 == 0 && b256 >= 2 * cus) code = 81;
+        if ((b256 >= cus && (a.N % 256 == 0 || (a.N % 128 != 0 && a.K >= 5760))) ||        // 256x256 phased: VAE 256/512-ch maps, 128x128-latent convs into 320 ch
+            (a.N % 256 == 0 && a.K >= 8192 && 2 * b256 >= cus)) code = 81;                  // ... and the long-K upsampling convs of the 32x32 level
         else if (a.N % 128 == 0 && b62 >= 150) code = 62;
+        else if (a.N % 128 == 0 && a.K >= 5760 && b51 >= 100) code = 51;                     // 32x32-latent convs: 160 x (128x128), 8 waves
+        else if (2 * b42 < 3 * cus) code = 43;                                               // stride-2 convs and other small grids
         else code = 42;
-    } else if (a.N % 256 == 0 && a.K >= 2048 && b256 >= 2 * cus) {
+    } else if (a.N % 256 == 0 && a.K >= 4096 && b256 >= cus) {
         code = 81;
-    } else if (a.N % 128 == 0 && a.N >= 1536 && a.K >= 512 && b62 >= 200) {
+    } else if (a.N % 128 == 0 && b62 >= 150 && (a.N >= 1536 || a.K >= 2048 || a.M >= 16384)) {
         code = 62;
-    } else if (a.N >= 2048 && a.K >= 1024 && blocks(128, 128) >= cus) {
+    } else if (a.N >= 2048 && a.K >= 1024 && b51 >= cus) {
         code = 51;
-    } else if (blocks(128, 64) >= cus * 7 / 2 || a.K >= 4096 || (a.K >= 1024 && blocks(128, 64) >= cus)) {
+    } else if (a.K <= 640 && a.N <= 640) {
+        code = 43;                                                                           // 64x64 / 128x128-latent projections: many small tiles
+    } else if (b42 >= cus * 7 / 2 || a.K >= 4096 || (a.K >= 1024 && b42 >= cus)) {
         code = 42;
     } else {
         code = 43;
@@ -370,6 +377,7 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     a.nbm = (a.M + t->bm - 1) / t->bm;
     a.nbn = (a.N + t->bn - 1) / t->bn;
     a.order = order;
+    a.probe = ctx->gemm_probe;
     snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 80 ? "gemm8_kernel" : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
              t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
     const dim3 grid((unsigned)(a.nbm * a.nbn)), block(256);
@@ -384,7 +392,8 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
         case 51: launch_ring<128, 128, 3, M3, 8>(ctx, a, grid); break;
         case 61: launch_ring<256, 256, 2, M3, 8>(ctx, a, grid); break;
         case 62: launch_ring<256, 128, 3, M3, 8>(ctx, a, grid); break;
-        case 81: return fie_launch_gemm8(ctx, a, MODE == 1);
+        case 81: return fie_launch_gemm8(ctx, a, MODE == 1, 0);
+        case 82: return fie_launch_gemm8(ctx, a, MODE == 1, 1);   // A/B: second DMA piece of a phase issued from inside the MFMA cluster (measured slower)
     }
     FIE_LAUNCH_CHECK();
     return FIE_OK;
@@ -470,6 +479,12 @@ int fie_debug_tile_override(fie_ctx* ctx, const char* spec) {
         if (*q == ';') ++q;
     }
     return ctx->n_overrides;
+}
+
+int fie_debug_gemm_probe(fie_ctx* ctx, int mode) {
+    FIE_REQUIRE(ctx != nullptr && mode >= 0 && mode <= 2, "fie_debug_gemm_probe: bad argument");
+    ctx->gemm_probe = mode;
+    return FIE_OK;
 }
 
 const char* fie_debug_last_gemm_kernel(fie_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }

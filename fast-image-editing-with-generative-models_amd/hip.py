@@ -58,6 +58,7 @@ SIGNATURES = {
     "fie_debug_gn_onepass": [_I],
     "fie_debug_tile_override": [_P, _c.c_char_p],
     "fie_debug_last_gemm_kernel": [_P],
+    "fie_debug_gemm_probe": [_P, _I],
 }
 
 _lib = None
@@ -138,6 +139,10 @@ class Context:
     def force_tile(self, code):
         """0 = heuristic; see include/fie.h for the codes.  An ineligible code makes the op raise FieError."""
         _chk(lib().fie_debug_force_tile(self.h, int(code)))
+
+    def gemm_probe(self, mode):
+        """TIMING-ONLY probes of the LDS-DMA GEMM kernels (outputs are wrong): 0 off, 1 loads dropped, 2 all tiles load tile (0,0)."""
+        _chk(lib().fie_debug_gemm_probe(self.h, int(mode)))
 
     def tile_override(self, spec):
         """"mode,M,N,K=code;..." per-shape tile codes (None clears).  Returns the number of entries parsed."""

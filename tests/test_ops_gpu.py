@@ -240,7 +240,7 @@ def test_clip_embed(fie):
     assert rel_err(out, ref) < 2e-3
 
 
-@pytest.mark.parametrize("code", [1, 2, 3, 41, 42, 43, 51, 61, 62, 81, 2042, 2081])
+@pytest.mark.parametrize("code", [1, 2, 3, 41, 42, 43, 51, 61, 62, 81, 82, 2042, 2081])
 def test_gemm_conv_every_shipped_kernel(fie, code):
     """Every kernel / tile the launch table can select (gemm_conv.hip kTiles; + 2000 = m-tiles-fastest order) gives the
     reference result on GEMMs with ragged M / N / K tails and on convs with stride 2, asymmetric pad and fused upsample; a
@@ -310,7 +310,8 @@ def test_phased_256x256_kernel_large_and_odd_ktiles(fie):
         # GEGLU epilogue
         m, n, k = 1024, 2560, 320
         a, w, bias = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5), rnd(n, seed=3)
-        out = fie.gemm(a.to(DEV), fie.pack_linear(w.to(DEV), geglu=True), n, bias=bias.to(DEV), act=hip.ACT_GEGLU)
+        bias_i = torch.stack([bias[: n // 2], bias[n // 2:]], 1).reshape(-1).contiguous()       # (value, gate) interleaved like the packed rows
+        out = fie.gemm(a.to(DEV), fie.pack_linear(w.to(DEV), geglu=True), n, bias=bias_i.to(DEV), act=hip.ACT_GEGLU)
         full = a.float() @ w.float().T + bias.float()
         assert rel_err(out, full[:, : n // 2] * F.gelu(full[:, n // 2:])) < 3e-3
         # identity activations x asymmetric weight: C must equal W^T exactly
@@ -405,14 +406,15 @@ def test_tile_override_steers_one_shape(fie):
     ad, bd = a.to(DEV), bias.to(DEV)
     wp = fie.pack_linear(w.to(DEV))
     ref = fie.gemm(ad, wp, n, bias=bd).clone()
-    default_kernel = hip.last_gemm_kernel(fie)
+    fie.gemm(ad[:256], wp, n, bias=bd)
+    default_small = hip.last_gemm_kernel(fie)
     try:
-        assert fie.tile_override(f"0,{m},{n},{k}=43;1,1,1,1=42") == 2
+        assert fie.tile_override(f"0,{m},{n},{k}=3;1,1,1,1=42") == 2
         out = fie.gemm(ad, wp, n, bias=bd).clone()
-        assert "tile code 43" in hip.last_gemm_kernel(fie)
-        other = fie.gemm(ad[:256], wp, n, bias=bd)            # a different M: not overridden
-        assert "tile code 43" not in hip.last_gemm_kernel(fie) or default_kernel.endswith("43)")
+        assert "tile code 3)" in hip.last_gemm_kernel(fie)
+        other = fie.gemm(ad[:256], wp, n, bias=bd).clone()            # a different M: not overridden
+        assert hip.last_gemm_kernel(fie) == default_small
     finally:
         assert fie.tile_override(None) == 0
-    assert rel_err(out, ref.float()) < 2e-3 and torch.equal(other, ref[:256]) or rel_err(other, ref[:256].float()) < 2e-3
+    assert rel_err(out, ref.float()) < 2e-3 and rel_err(other, ref[:256].float()) < 2e-3
     assert rel_err(ref, a.float() @ w.float().T + bias.float()) < 3e-3
