@@ -5,6 +5,7 @@
 
 int fie_gemm_init(void);
 int fie_gemm8_init(void);
+int fie_gemm_w8_init(void);
 
 static thread_local char g_err[512] = "";
 
@@ -47,6 +48,7 @@ int fie_ctx_create(int device, void* stream, fie_ctx** out) {
     }
     int rc = fie_gemm_init();
     if (rc == FIE_OK) rc = fie_gemm8_init();
+    if (rc == FIE_OK) rc = fie_gemm_w8_init();
     (void)hipSetDevice(cur);
     if (rc != FIE_OK) return rc;
     fie_ctx* c = new fie_ctx();

@@ -29,6 +29,7 @@ struct GemmArgs {
     float scale; int act;
     int nbm, nbn;
     int64_t a1_bytes, a2_bytes, w_bytes;   // operand extents for the v3 buffer descriptors
+    const float* w_scale;                   // fp8 weights (gemm_w8.hip): per-output-channel dequantisation scale [N], applied to the accumulator first; Wt then points at e4m3 bytes and ldw counts bytes
     int probe;                              // timing-only probes (fie_debug_gemm_probe; outputs are wrong): 1 = every DMA load dropped (zero-record descriptors), 2 = every tile fetches tile (0,0)'s operands (all L2 hits)
     int order;                              // 0: n-tiles fastest (an XCD owns a range of rows), 1: m-tiles fastest (an XCD owns a range of columns)
 };
@@ -50,6 +51,10 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
             const int n = n0 + wn * WN + i * 16 + fq * 4;
             if (n >= p.N) continue;
             f32x4 v = acc[i][j];
+            if (p.w_scale) {
+                const float4 ws = *reinterpret_cast<const float4*>(p.w_scale + n);
+                v[0] *= ws.x; v[1] *= ws.y; v[2] *= ws.z; v[3] *= ws.w;
+            }
             if (p.bias) {
                 const f16x4 b = *reinterpret_cast<const f16x4*>(p.bias + n);
 #pragma unroll
@@ -121,3 +126,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 int fie_launch_gemm8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int conv, int split);
 int fie_gemm8_init(void);          // per-device function attributes (dynamic LDS size); called from fie_ctx_create
 int fie_gemm_init(void);           // same for the kernels of gemm_conv.hip
+// gemm_w8.hip: fp8-weight ring kernels; code 62 = 256x128 (8 waves), 42 = 128x64, 43 = 64x64
+int fie_launch_gemm_w8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int conv, int code);
+int fie_gemm_w8_init(void);

@@ -374,12 +374,22 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     FIE_REQUIRE(t != nullptr, "unknown tile code %d", code);
     FIE_REQUIRE(code < 40 || dma_ok, "tile code %d: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)", code);
     (void)forced;
+    if (a.w_scale) {                 // fp8 weights: the three W8 ring tiles (gemm_w8.hip)
+        FIE_REQUIRE(dma_ok, "fp8 weights: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)");
+        code = (code == 81 || code == 82 || code == 61 || code == 62) ? 62 : (code == 43 || code == 3) ? 43 : 42;
+        for (const TileDim& d : kTiles)
+            if (d.code == code) t = &d;
+    }
     a.nbm = (a.M + t->bm - 1) / t->bm;
     a.nbn = (a.N + t->bn - 1) / t->bn;
     a.order = order;
     a.probe = ctx->gemm_probe;
     snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 80 ? "gemm8_kernel" : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
              t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
+    if (a.w_scale) {
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "gemm3w8_kernel<%dx%d> (%s, fp8 weights, tile code %d)", t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
+        return fie_launch_gemm_w8(ctx, a, MODE == 1, code);
+    }
     const dim3 grid((unsigned)(a.nbm * a.nbn)), block(256);
     constexpr int M3 = MODE == 1 ? 2 : 0;
     switch (code) {
@@ -489,60 +499,89 @@ int fie_debug_gemm_probe(fie_ctx* ctx, int mode) {
 
 const char* fie_debug_last_gemm_kernel(fie_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }
 
-int fie_gemm_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2,
-                 const void* Wpacked, int64_t ldw, void* C, int64_t ldc, int M, int N, int K, const void* bias,
-                 const void* rowbias, int64_t ld_rowbias, int rows_per_batch, const void* residual, int64_t ldr,
-                 float scale, int act) {
-    FIE_REQUIRE(ctx && A1 && Wpacked && C, "fie_gemm_f16: NULL ctx/A1/W/C");
-    FIE_REQUIRE(M > 0 && N > 0 && K > 0, "fie_gemm_f16: bad shape M=%d N=%d K=%d", M, N, K);
-    FIE_REQUIRE(K % 8 == 0 && K1 % 8 == 0 && K1 > 0 && K1 <= K, "fie_gemm_f16: K=%d K1=%d must be multiples of 8", K, K1);
-    FIE_REQUIRE(lda1 % 8 == 0 && lda1 >= K1, "fie_gemm_f16: lda1=%lld invalid", (long long)lda1);
-    FIE_REQUIRE(K1 == K || (A2 && lda2 % 8 == 0 && lda2 >= K - K1), "fie_gemm_f16: A2/lda2 invalid for K1 < K");
-    FIE_REQUIRE(ldw % BK == 0 && ldw >= K, "fie_gemm_f16: ldw=%lld must be a multiple of 64 covering K", (long long)ldw);
-    FIE_REQUIRE(!rowbias || rows_per_batch > 0, "fie_gemm_f16: rowbias needs rows_per_batch");
-    if (int e = check_epilogue("fie_gemm_f16", N, ldc, residual, ldr, act)) return e;
+static int gemm_impl(const char* who, fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2,
+                     const void* Wpacked, int64_t ldw, const float* w_scale, void* C, int64_t ldc, int M, int N, int K, const void* bias,
+                     const void* rowbias, int64_t ld_rowbias, int rows_per_batch, const void* residual, int64_t ldr, float scale, int act) {
+    FIE_REQUIRE(ctx && A1 && Wpacked && C, "%s: NULL ctx/A1/W/C", who);
+    FIE_REQUIRE(M > 0 && N > 0 && K > 0, "%s: bad shape M=%d N=%d K=%d", who, M, N, K);
+    FIE_REQUIRE(K % 8 == 0 && K1 % 8 == 0 && K1 > 0 && K1 <= K, "%s: K=%d K1=%d must be multiples of 8", who, K, K1);
+    FIE_REQUIRE(lda1 % 8 == 0 && lda1 >= K1, "%s: lda1=%lld invalid", who, (long long)lda1);
+    FIE_REQUIRE(K1 == K || (A2 && lda2 % 8 == 0 && lda2 >= K - K1), "%s: A2/lda2 invalid for K1 < K", who);
+    FIE_REQUIRE(ldw % BK == 0 && ldw >= K, "%s: ldw=%lld must be a multiple of 64 covering K", who, (long long)ldw);
+    FIE_REQUIRE(!rowbias || rows_per_batch > 0, "%s: rowbias needs rows_per_batch", who);
+    if (int e = check_epilogue(who, N, ldc, residual, ldr, act)) return e;
     GemmArgs a = {};
     a.A1 = (const half_t*)A1; a.lda1 = lda1; a.K1 = K1; a.A2 = (const half_t*)A2; a.lda2 = lda2;
-    a.Wt = (const half_t*)Wpacked; a.ldw = ldw; a.C = (half_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.Wt = (const half_t*)Wpacked; a.ldw = ldw; a.w_scale = w_scale; a.C = (half_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
     a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
     a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     a.res = (const half_t*)residual; a.ldr = ldr; a.scale = scale; a.act = act;
     a.a1_bytes = ((int64_t)(M - 1) * lda1 + K1) * 2;
     a.a2_bytes = A2 ? ((int64_t)(M - 1) * lda2 + (K - K1)) * 2 : 0;
-    a.w_bytes = fie_roundup(N, 128) * ldw * 2;
+    a.w_bytes = fie_roundup(N, 128) * ldw * (w_scale ? 1 : 2);
     return launch<0>(ctx, a);
+}
+
+int fie_gemm_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2,
+                 const void* Wpacked, int64_t ldw, void* C, int64_t ldc, int M, int N, int K, const void* bias,
+                 const void* rowbias, int64_t ld_rowbias, int rows_per_batch, const void* residual, int64_t ldr,
+                 float scale, int act) {
+    return gemm_impl("fie_gemm_f16", ctx, A1, lda1, K1, A2, lda2, Wpacked, ldw, nullptr, C, ldc, M, N, K, bias, rowbias, ld_rowbias,
+                     rows_per_batch, residual, ldr, scale, act);
+}
+
+int fie_gemm_w8_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, const void* W8packed,
+                    int64_t ldw, const float* w_scale, void* C, int64_t ldc, int M, int N, int K, const void* bias, const void* rowbias,
+                    int64_t ld_rowbias, int rows_per_batch, const void* residual, int64_t ldr, float scale, int act) {
+    FIE_REQUIRE(w_scale != nullptr, "fie_gemm_w8_f16: w_scale is NULL");
+    return gemm_impl("fie_gemm_w8_f16", ctx, A1, lda1, K1, A2, lda2, W8packed, ldw, w_scale, C, ldc, M, N, K, bias, rowbias, ld_rowbias,
+                     rows_per_batch, residual, ldr, scale, act);
+}
+
+static int conv_impl(const char* who, fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, int upsample2x, int stride, int pad_mode,
+                     const void* Wpacked, int64_t ldw, const float* w_scale, void* Y, int64_t ldc, int Cout, const void* bias,
+                     const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ldr, float scale, int act) {
+    FIE_REQUIRE(ctx && X && Wpacked && Y, "%s: NULL ctx/X/W/Y", who);
+    FIE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "%s: bad shape", who);
+    FIE_REQUIRE(Cin % 8 == 0, "%s: Cin=%d must be a multiple of 8 (pad the tensor)", who, Cin);
+    FIE_REQUIRE(stride == 1 || stride == 2, "%s: stride %d", who, stride);
+    FIE_REQUIRE(pad_mode == 0 || pad_mode == 1, "%s: pad_mode %d", who, pad_mode);
+    FIE_REQUIRE(act != FIE_ACT_GEGLU, "%s: GEGLU not supported", who);
+    const int K = 9 * Cin;
+    FIE_REQUIRE(ldw % BK == 0 && ldw >= K, "%s: ldw=%lld must be a multiple of 64 covering 9*Cin", who, (long long)ldw);
+    if (int e = check_epilogue(who, Cout, ldc, residual, ldr, act)) return e;
+    const int ups = upsample2x ? 1 : 0;
+    const int Hin = H << ups, Win = W << ups;
+    const int pads = pad_mode == 0 ? 2 : 1;
+    const int OH = (Hin + pads - 3) / stride + 1, OW = (Win + pads - 3) / stride + 1;
+    FIE_REQUIRE((int64_t)B * OH * OW < (1ll << 31), "%s: too many output pixels", who);
+    GemmArgs a = {};
+    a.A1 = (const half_t*)X; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.stride = stride;
+    a.pt = a.pl = pad_mode == 0 ? 1 : 0; a.ups = ups;
+    a.Wt = (const half_t*)Wpacked; a.ldw = ldw; a.w_scale = w_scale; a.C = (half_t*)Y; a.ldc = ldc;
+    a.M = B * OH * OW; a.N = Cout; a.K = K; a.K1 = K;
+    a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
+    a.rows_per_batch = OH * OW; a.res = (const half_t*)residual; a.ldr = ldr; a.scale = scale; a.act = act;
+    a.a1_bytes = (int64_t)B * H * W * Cin * 2;
+    a.a2_bytes = 0;
+    a.w_bytes = fie_roundup(Cout, 128) * ldw * (w_scale ? 1 : 2);
+    return launch<1>(ctx, a);
 }
 
 int fie_conv3x3_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, int upsample2x, int stride,
                          int pad_mode, const void* Wpacked, int64_t ldw, void* Y, int64_t ldc, int Cout,
                          const void* bias, const void* rowbias, int64_t ld_rowbias, const void* residual,
                          int64_t ldr, float scale, int act) {
-    FIE_REQUIRE(ctx && X && Wpacked && Y, "fie_conv3x3_nhwc_f16: NULL ctx/X/W/Y");
-    FIE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "fie_conv3x3_nhwc_f16: bad shape");
-    FIE_REQUIRE(Cin % 8 == 0, "fie_conv3x3_nhwc_f16: Cin=%d must be a multiple of 8 (pad the tensor)", Cin);
-    FIE_REQUIRE(stride == 1 || stride == 2, "fie_conv3x3_nhwc_f16: stride %d", stride);
-    FIE_REQUIRE(pad_mode == 0 || pad_mode == 1, "fie_conv3x3_nhwc_f16: pad_mode %d", pad_mode);
-    FIE_REQUIRE(act != FIE_ACT_GEGLU, "fie_conv3x3_nhwc_f16: GEGLU not supported");
-    const int K = 9 * Cin;
-    FIE_REQUIRE(ldw % BK == 0 && ldw >= K, "fie_conv3x3_nhwc_f16: ldw=%lld must be a multiple of 64 covering 9*Cin",
-                (long long)ldw);
-    if (int e = check_epilogue("fie_conv3x3_nhwc_f16", Cout, ldc, residual, ldr, act)) return e;
-    const int ups = upsample2x ? 1 : 0;
-    const int Hin = H << ups, Win = W << ups;
-    const int pads = pad_mode == 0 ? 2 : 1;
-    const int OH = (Hin + pads - 3) / stride + 1, OW = (Win + pads - 3) / stride + 1;
-    FIE_REQUIRE((int64_t)B * OH * OW < (1ll << 31), "fie_conv3x3_nhwc_f16: too many output pixels");
-    GemmArgs a = {};
-    a.A1 = (const half_t*)X; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.stride = stride;
-    a.pt = a.pl = pad_mode == 0 ? 1 : 0; a.ups = ups;
-    a.Wt = (const half_t*)Wpacked; a.ldw = ldw; a.C = (half_t*)Y; a.ldc = ldc;
-    a.M = B * OH * OW; a.N = Cout; a.K = K; a.K1 = K;
-    a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
-    a.rows_per_batch = OH * OW; a.res = (const half_t*)residual; a.ldr = ldr; a.scale = scale; a.act = act;
-    a.a1_bytes = (int64_t)B * H * W * Cin * 2;
-    a.a2_bytes = 0;
-    a.w_bytes = fie_roundup(Cout, 128) * ldw * 2;
-    return launch<1>(ctx, a);
+    return conv_impl("fie_conv3x3_nhwc_f16", ctx, X, B, H, W, Cin, upsample2x, stride, pad_mode, Wpacked, ldw, nullptr, Y, ldc, Cout, bias,
+                     rowbias, ld_rowbias, residual, ldr, scale, act);
+}
+
+int fie_conv3x3_w8_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, int upsample2x, int stride, int pad_mode,
+                            const void* W8packed, int64_t ldw, const float* w_scale, void* Y, int64_t ldc, int Cout, const void* bias,
+                            const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ldr, float scale, int act) {
+    FIE_REQUIRE(w_scale != nullptr, "fie_conv3x3_w8_nhwc_f16: w_scale is NULL");
+    return conv_impl("fie_conv3x3_w8_nhwc_f16", ctx, X, B, H, W, Cin, upsample2x, stride, pad_mode, W8packed, ldw, w_scale, Y, ldc, Cout,
+                     bias, rowbias, ld_rowbias, residual, ldr, scale, act);
 }
 
 int fie_pack_rows_f16(fie_ctx* ctx, const void* src, int64_t ld_src, int N, int K, void* dst, int64_t ldw,

@@ -26,6 +26,10 @@ SIGNATURES = {
     "fie_ctx_destroy": [_P],
     "fie_gemm_f16": [_P, _P, _L, _I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _P, _L, _F, _I],
     "fie_conv3x3_nhwc_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P, _P, _L, _P, _L, _F, _I],
+    "fie_pack_rows_f8": [_P, _P, _L, _I, _I, _P, _L, _I, _P, _I],
+    "fie_pack_conv3x3_f8": [_P, _P, _I, _I, _I, _P, _L, _I, _P],
+    "fie_gemm_w8_f16": [_P, _P, _L, _I, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P, _P, _L, _I, _P, _L, _F, _I],
+    "fie_conv3x3_w8_nhwc_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P, _P, _L, _P, _L, _F, _I],
     "fie_attention_f16": [_P, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I],
     "fie_groupnorm_workspace_bytes": [_I, _L, _I],
     "fie_groupnorm_nhwc_f16": [_P, _P, _I, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P],
@@ -110,6 +114,20 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+class W8:
+    """A packed fp8 (e4m3) weight: bytes [Npad, Kpad] + one fp32 dequantisation scale per output channel (include/fie.h,
+    fie_pack_*_f8).  `stride(0)` mirrors the packed fp16 tensors so call sites stay the same."""
+
+    def __init__(self, q, scale):
+        self.q, self.scale = q, scale
+
+    def stride(self, d):
+        return self.q.stride(d)
+
+    def dequant(self):
+        return self.q.view(torch.float8_e4m3fn).float() * self.scale[:, None]
+
+
 class Context:
     """One fie_ctx per (process, device); launches go to torch's current stream on that device."""
 
@@ -128,6 +146,7 @@ class Context:
         self._gn_ws = {}
         self._resize_tables = {}       # (in, out) -> (taps, bounds, ksize) of the LANCZOS resample, on the device
         self.ws_tag = 0
+        self.w8 = False                # while True, pack_linear / pack_conv3x3 quantise eligible weights to fp8 e4m3 (see W8)
 
     def sync_stream(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
@@ -154,7 +173,7 @@ class Context:
             self.h = None
 
     # ------------------------------------------------------------------ weight packing
-    def pack_linear(self, w, geglu=False):
+    def pack_linear(self, w, geglu=False, quant=True):
         """[N, K] f16 -> packed [Npad][Kpad] (zero padded); geglu interleaves (value, gate) rows.
         fp32 contexts keep plain [N, K] fp32 weights (rows interleaved for GEGLU)."""
         self.sync_stream()
@@ -167,6 +186,11 @@ class Context:
         w = w.to(self.device, torch.float16).contiguous()
         n, k = w.shape
         npad, kpad = (n + 127) // 128 * 128, (k + 63) // 64 * 64
+        if self.w8 and quant:
+            q = torch.empty((npad, kpad), device=self.device, dtype=torch.uint8)
+            scale = torch.empty((npad,), device=self.device, dtype=torch.float32)
+            _chk(lib().fie_pack_rows_f8(self.h, _p(w), k, n, k, _p(q), kpad, npad, _p(scale), int(geglu)))
+            return W8(q, scale)
         out = torch.empty((npad, kpad), device=self.device, dtype=torch.float16)
         _chk(lib().fie_pack_rows_f16(self.h, _p(w), k, n, k, _p(out), kpad, npad, int(geglu)))
         return out
@@ -184,6 +208,11 @@ class Context:
         co, ci = w.shape[:2]
         cin_pad = cin_pad or (ci + 7) // 8 * 8
         npad, kpad = (co + 127) // 128 * 128, (9 * cin_pad + 63) // 64 * 64
+        if self.w8 and cin_pad % 64 == 0:          # the fp8 kernels are the LDS-DMA ones: K-steps must not straddle a 3x3 tap
+            q = torch.empty((npad, kpad), device=self.device, dtype=torch.uint8)
+            scale = torch.empty((npad,), device=self.device, dtype=torch.float32)
+            _chk(lib().fie_pack_conv3x3_f8(self.h, _p(w), co, ci, cin_pad, _p(q), kpad, npad, _p(scale)))
+            return W8(q, scale)
         out = torch.empty((npad, kpad), device=self.device, dtype=torch.float16)
         _chk(lib().fie_pack_conv3x3_f16(self.h, _p(w), co, ci, cin_pad, _p(out), kpad, npad))
         return out
@@ -207,6 +236,12 @@ class Context:
                                     rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
                                     residual.stride(0) if residual is not None else 0, float(scale), act, 1, 1, 0, 0, 0, 0, 0, 0))
             return out
+        if isinstance(wp, W8):
+            _chk(lib().fie_gemm_w8_f16(self.h, _p(a), a.stride(0), k1, _p(a2), a2.stride(0) if a2 is not None else 0,
+                                       _p(wp.q), wp.stride(0), _p(wp.scale), _p(out), out.stride(0), m, n, ktot, _p(bias), _p(rowbias),
+                                       rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
+                                       residual.stride(0) if residual is not None else 0, float(scale), act))
+            return out
         _chk(lib().fie_gemm_f16(self.h, _p(a), a.stride(0), k1, _p(a2), a2.stride(0) if a2 is not None else 0,
                                 _p(wp), wp.stride(0), _p(out), out.stride(0), m, n, ktot, _p(bias), _p(rowbias),
                                 rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
@@ -225,6 +260,12 @@ class Context:
         ldc = ldc or cout
         if out is None:
             out = (torch.zeros if ldc != cout else torch.empty)((b, oh, ow, ldc), device=x.device, dtype=self.dtype)
+        if isinstance(wp, W8):
+            _chk(lib().fie_conv3x3_w8_nhwc_f16(self.h, _p(x), b, h, w, cin, int(upsample), stride, pad_mode, _p(wp.q), wp.stride(0),
+                                               _p(wp.scale), _p(out), out.stride(2), cout, _p(bias), _p(rowbias),
+                                               rowbias.stride(0) if rowbias is not None else 0, _p(residual),
+                                               residual.stride(2) if residual is not None else 0, float(scale), act))
+            return out
         fn = lib().fie_conv3x3_nhwc_f32 if self.f32 else lib().fie_conv3x3_nhwc_f16
         _chk(fn(self.h, _p(x), b, h, w, cin, int(upsample), stride, pad_mode, _p(wp),
                                         wp.stride(0), _p(out), out.stride(2), cout, _p(bias), _p(rowbias),

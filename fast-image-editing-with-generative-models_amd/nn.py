@@ -23,13 +23,15 @@ def _dev(ctx, t):
 
 
 class Linear:
-    def __init__(self, ctx, sd, name, geglu=False, w=None, b=None):
+    def __init__(self, ctx, sd, name, geglu=False, w=None, b=None, quant=True):
+        """quant=False keeps the weight fp16 even while the context packs fp8 weights (`ctx.w8`): the M = batch-rows embedding
+        MLPs, whose outputs condition every layer."""
         w = sd[name + ".weight"] if w is None else w
         b = sd.get(name + ".bias") if b is None and name else b
         w = w.reshape(w.shape[0], -1)
         self.n, self.k = w.shape
         self.act = hip.ACT_GEGLU if geglu else hip.ACT_NONE
-        self.wp = ctx.pack_linear(w, geglu=geglu)
+        self.wp = ctx.pack_linear(w, geglu=geglu, quant=quant)
         if b is not None:
             b = _dev(ctx, b)
             if geglu:
@@ -150,8 +152,8 @@ class _CondNet:
         chans = cfg["block_out_channels"]
         self.temb_names = []                      # resnet prefixes in fused-projection order
         self.conv_in = Conv3(ctx, sd, "conv_in", cin_pad=8)
-        self.t1, self.t2 = Linear(ctx, sd, "time_embedding.linear_1"), Linear(ctx, sd, "time_embedding.linear_2")
-        self.a1, self.a2 = Linear(ctx, sd, "add_embedding.linear_1"), Linear(ctx, sd, "add_embedding.linear_2")
+        self.t1, self.t2 = Linear(ctx, sd, "time_embedding.linear_1", quant=False), Linear(ctx, sd, "time_embedding.linear_2", quant=False)
+        self.a1, self.a2 = Linear(ctx, sd, "add_embedding.linear_1", quant=False), Linear(ctx, sd, "add_embedding.linear_2", quant=False)
         self.down = []
         for i in range(len(chans)):
             layers = []
@@ -183,7 +185,7 @@ class _CondNet:
             bs.append(sd[p + "time_emb_proj.bias"])
             r.temb_slot = (col, col + w.shape[0])
             col += w.shape[0]
-        self.temb_proj = Linear(self.ctx, None, None, w=torch.cat(ws, 0), b=torch.cat(bs, 0))
+        self.temb_proj = Linear(self.ctx, None, None, w=torch.cat(ws, 0), b=torch.cat(bs, 0), quant=False)
         self._sd = None
 
     def transformers(self):

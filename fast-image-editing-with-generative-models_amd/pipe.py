@@ -22,11 +22,22 @@ F16 = torch.float16
 
 
 class HipImg2ImgPipeline:
-    def __init__(self, ctx, cfgs, sds, tokenizers=None, sched_cfg=None, noise_dtype=None):
-        """cfgs / sds: dicts with keys unet, controlnet, vae, clip_l, clip_g (configs / diffusers-named state dicts)."""
-        self.ctx, self.cfgs = ctx, cfgs
-        self.unet = UNet(ctx, cfgs["unet"], sds["unet"])
-        self.controlnet = ControlNet(ctx, cfgs["controlnet"], sds["controlnet"])
+    def __init__(self, ctx, cfgs, sds, tokenizers=None, sched_cfg=None, noise_dtype=None, weight_dtype="f16"):
+        """cfgs / sds: dicts with keys unet, controlnet, vae, clip_l, clip_g (configs / diffusers-named state dicts).
+        weight_dtype "f8e4m3" (BASELINE config 5): the Linear / conv weights of the UNet and the ControlNet are stored as fp8 e4m3
+        with per-output-channel scales and multiplied on the fp8 MFMA (csrc/gemm_w8.hip); VAE, text encoders, embedding MLPs and
+        the few convs the LDS-DMA kernels cannot address (Cin % 64 != 0) stay fp16."""
+        if weight_dtype not in ("f16", "f8e4m3"):
+            raise ValueError(f"weight_dtype {weight_dtype!r}: 'f16' or 'f8e4m3'")
+        if weight_dtype != "f16" and ctx.f32:
+            raise ValueError("fp8 weights belong to the fp16 path")
+        self.ctx, self.cfgs, self.weight_dtype = ctx, cfgs, weight_dtype
+        ctx.w8 = weight_dtype == "f8e4m3"
+        try:
+            self.unet = UNet(ctx, cfgs["unet"], sds["unet"])
+            self.controlnet = ControlNet(ctx, cfgs["controlnet"], sds["controlnet"])
+        finally:
+            ctx.w8 = False
         self.vae = VAE(ctx, cfgs["vae"], sds["vae"])
         self.clip_l = ClipText(ctx, cfgs["clip_l"], sds["clip_l"])
         self.clip_g = ClipText(ctx, cfgs["clip_g"], sds["clip_g"])

@@ -131,6 +131,26 @@ int fie_pack_rows_f16(fie_ctx* ctx, const void* src, int64_t ld_src, int N, int 
 int fie_pack_conv3x3_f16(fie_ctx* ctx, const void* src_oihw, int Cout, int Cin, int cin_pad, void* dst,
                          int64_t ldw, int Npad);
 
+/* ---- fp8 (OCP e4m3) WEIGHTS on the fp8 MFMA: BASELINE.json config 5, the low-precision stretch beside the precision choice at
+ * /root/reference/src/pipeline.py:67-71 (`FastEditor(..., weight_dtype="f8e4m3")`, additive).  Weights are e4m3 with one fp32
+ * scale per output channel (scale[n] = max_k |W[n,k]| / 448); activations stay fp16 in HBM and are converted to e4m3 per fragment
+ * in registers (saturating RNE, scale 1) for v_mfma_f32_16x16x32_fp8_fp8; fp32 accumulation;  epi(v) takes v * scale[n].
+ *   fie_pack_rows_f8 / fie_pack_conv3x3_f8: as their _f16 twins, dst = [Npad][ldw] BYTES (ldw % 64 == 0), scales = [Npad] fp32 (out).
+ *   fie_gemm_w8_f16 / fie_conv3x3_w8_nhwc_f16: as fie_gemm_f16 / fie_conv3x3_nhwc_f16 with (W8packed, ldw in bytes, w_scale).
+ *   Shapes must be eligible for the LDS-DMA kernels (operands < 2 GiB, Cin % 64 == 0, K1 == K or K1 % 64 == 0), else FIE_EINVAL. */
+int fie_pack_rows_f8(fie_ctx* ctx, const void* src, int64_t ld_src, int N, int K, void* dst, int64_t ldw, int Npad, float* scales,
+                     int interleave2);
+int fie_pack_conv3x3_f8(fie_ctx* ctx, const void* src_oihw, int Cout, int Cin, int cin_pad, void* dst, int64_t ldw, int Npad,
+                        float* scales);
+int fie_gemm_w8_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, const void* W8packed,
+                    int64_t ldw, const float* w_scale, void* C, int64_t ldc, int M, int N, int K, const void* bias,
+                    const void* rowbias, int64_t ld_rowbias, int rows_per_batch, const void* residual, int64_t ldr, float scale,
+                    int act);
+int fie_conv3x3_w8_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, int upsample2x, int stride, int pad_mode,
+                            const void* W8packed, int64_t ldw, const float* w_scale, void* Y, int64_t ldc, int Cout,
+                            const void* bias, const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ldr,
+                            float scale, int act);
+
 /* ---- fp32 path (`FastEditor(use_full_precision=True)`, run_batch.py --full_precision / --quality_mode; reference:
  * src/pipeline.py:67-71,94-99).  Same graphs, fp32 storage, exact fp32 arithmetic on v_mfma_f32_16x16x4_f32.
  *   fie_gemm_f32: as fie_gemm_f16 with plain (unpacked) weights W [N][ldw] -- or [K][ldw] when w_is_kn -- and a two-level

@@ -3,7 +3,7 @@
 Same constructor, `MODEL_CONFIGS`, `edit()` / `preprocess_image()` / `clear_memory()` / `get_memory_usage()`
 signatures, defaults, attributes and error behaviour; `self.pipe` is an `fie_amd.pipe.HipImg2ImgPipeline`
 (hand-written HIP kernels behind a C ABI) instead of the diffusers pipeline.  There is no CPU fallback: a missing
-HIP library or GPU raises.  Additive: `set_in_flight(n)` / `worker_slot(i)` (several edits in flight from worker threads), and keyword-only knobs: `weights_dir`, `seed_weights`, `noise_dtype`, `broadcast_weights`
+HIP library or GPU raises.  Additive: `set_in_flight(n)` / `worker_slot(i)` (several edits in flight from worker threads), and keyword-only knobs: `weights_dir`, `seed_weights`, `noise_dtype`, `weight_dtype` ("f8e4m3": fp8 UNet / ControlNet weights, BASELINE config 5), `broadcast_weights`
 (under torch.distributed with world_size > 1, rank 0's synthetic weights are broadcast over RCCL instead of regenerated).
 """
 import os
@@ -40,7 +40,7 @@ class FastEditor:
 
     def __init__(self, model_name="sdxl", device="cuda", dtype=torch.float16, enable_cpu_offload=True,
                  use_full_precision=False, use_full_controlnet=False, *, weights_dir=None, seed_weights=1234,
-                 noise_dtype=None, broadcast_weights=True):
+                 noise_dtype=None, broadcast_weights=True, weight_dtype="f16"):
         if model_name not in self.MODEL_CONFIGS and model_name not in self._EXTRA_STACKS:
             raise ValueError(f"Unknown model: {model_name}. Choose from {list(self.MODEL_CONFIGS.keys())}")
         self.model_name = model_name
@@ -91,7 +91,10 @@ class FastEditor:
                 cfgs, sds = stack.synthetic_stack(model_name, use_full_controlnet, device=ctx.device, dtype=self.dtype, seed=seed_weights)
         self.presets = {k: c["name"] for k, c in cfgs.items()}
         log("Setting LCM scheduler...")
-        self.pipe = HipImg2ImgPipeline(ctx, cfgs, sds, tokenizers=toks, noise_dtype=noise_dtype or self.dtype)
+        if weight_dtype != "f16":
+            log(f"UNet / ControlNet weights: {weight_dtype} with per-channel scales on the fp8 MFMA (BASELINE config 5)")
+        self.weight_dtype = weight_dtype
+        self.pipe = HipImg2ImgPipeline(ctx, cfgs, sds, tokenizers=toks, noise_dtype=noise_dtype or self.dtype, weight_dtype=weight_dtype)
         self.controlnet = self.pipe.controlnet
         self._tls = threading.local()          # .slot: graph slot of the calling worker thread (set_in_flight)
         del sds
