@@ -22,6 +22,78 @@ __global__ void sinusoid_kernel(const float* vals, int B, int nvals, int dim, T*
     row[half + f] = (T)sinf(arg);
 }
 
+// K7, fused (north_star: "timestep-embedding fused into wavefront-level HIP kernels"): per denoising step
+//     out[b, :] = SiLU( W2 SiLU(W1 sinus(t_b) + b1) + b2 + add[b, :] )
+// = Timesteps(C0, flip_sin_to_cos, shift 0) -> TimestepEmbedding (Linear, SiLU, Linear) -> + text-time embedding -> the SiLU every
+// resnet applies in front of its time projection (upstream embeddings.py, resnet.py) -- ONE launch instead of sinusoid + two GEMM
+// launches whose M is the batch (2 rows).  One wave per output neuron: lanes stride the K dimension in 16-byte vectors, fp32
+// accumulation, wave reduction by shuffles.  Every block evaluates layer 1 completely (E x C0 MACs per row; W1's 0.8 MB stay in L2)
+// and 64 neurons of layer 2; the intermediate vectors are rounded to the storage type exactly where the unfused path stores them.
+constexpr int kTeMaxB = 16;
+
+__global__ __launch_bounds__(256) void time_embed_kernel(const float* t, int B, int C0, int E, const half_t* W1, const half_t* b1,
+                                                         const half_t* W2, const half_t* b2, const half_t* add, int64_t ld_add,
+                                                         half_t* out, int64_t ld_out) {
+    extern __shared__ __attribute__((aligned(16))) half_t te_smem[];
+    half_t* x = te_smem;                       // [B][C0]
+    half_t* h = te_smem + B * C0;              // [B][E]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half_c = C0 / 2;
+    for (int i = tid; i < B * half_c; i += 256) {
+        const int b = i / half_c, f = i - b * half_c;
+        const float arg = t[b] * expf(-9.210340371976184f * (float)f / (float)half_c);
+        x[b * C0 + f] = (half_t)cosf(arg);
+        x[b * C0 + half_c + f] = (half_t)sinf(arg);
+    }
+    __syncthreads();
+    auto dot_rows = [&](const half_t* wrow, const half_t* vec, int K, float (&acc)[kTeMaxB]) {
+#pragma unroll
+        for (int b = 0; b < kTeMaxB; ++b) acc[b] = 0.f;
+        for (int k = lane * 8; k < K; k += 512) {
+            float w[8];
+            fie_load8(wrow + k, w);
+#pragma unroll
+            for (int b = 0; b < kTeMaxB; ++b) {
+                if (b < B) {
+                    float v[8];
+                    fie_load8(vec + b * K + k, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[b] += w[j] * v[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < kTeMaxB; ++b)
+            if (b < B) {
+#pragma unroll
+                for (int o = 32; o; o >>= 1) acc[b] += __shfl_xor(acc[b], o);
+            }
+    };
+    float acc[kTeMaxB];
+    for (int n = wave; n < E; n += 4) {                                  // layer 1, all of it
+        dot_rows(W1 + (int64_t)n * C0, x, C0, acc);
+        if (lane < B) {
+            float v = 0.f;
+#pragma unroll
+            for (int b = 0; b < kTeMaxB; ++b) v = lane == b ? acc[b] : v;
+            h[lane * E + n] = (half_t)fie_silu(v + (float)b1[n]);
+        }
+    }
+    __syncthreads();
+    for (int q = wave; q < 64; q += 4) {                                 // layer 2, this block's 64 neurons
+        const int n = blockIdx.x * 64 + q;
+        if (n >= E) break;
+        dot_rows(W2 + (int64_t)n * E, h, E, acc);
+        if (lane < B) {
+            float v = 0.f;
+#pragma unroll
+            for (int b = 0; b < kTeMaxB; ++b) v = lane == b ? acc[b] : v;
+            v += (float)b2[n] + (add ? (float)add[(int64_t)lane * ld_add + n] : 0.f);
+            out[(int64_t)lane * ld_out + n] = (half_t)fie_silu(v);
+        }
+    }
+}
+
 template <typename E>
 __global__ void clip_embed_kernel(const int32_t* ids, int rows, int T, int C, const E* tok, const E* pos, E* out) {
     const int nch = C >> 3;
@@ -201,6 +273,18 @@ int fie_sinusoid_f16(fie_ctx* ctx, const float* vals, int B, int nvals, int dim,
 }
 int fie_sinusoid_f32(fie_ctx* ctx, const float* vals, int B, int nvals, int dim, void* out, int64_t ld_out, int col0) {
     return sinusoid_t<float>(ctx, vals, B, nvals, dim, out, ld_out, col0);
+}
+int fie_time_embed_f16(fie_ctx* ctx, const float* t, int B, int C0, int E, const void* W1, const void* b1, const void* W2, const void* b2,
+                       const void* add, int64_t ld_add, void* out, int64_t ld_out) {
+    FIE_REQUIRE(ctx && t && W1 && b1 && W2 && b2 && out, "fie_time_embed_f16: NULL argument");
+    FIE_REQUIRE(B > 0 && B <= kTeMaxB && C0 > 0 && C0 % 16 == 0 && E > 0 && E % 8 == 0 && ld_out >= E && (!add || ld_add >= E),
+                "fie_time_embed_f16: bad shape (B <= %d, C0 %% 16 == 0, E %% 8 == 0)", kTeMaxB);
+    const int lds = B * (C0 + E) * (int)sizeof(half_t);
+    FIE_REQUIRE(lds <= 64 * 1024, "fie_time_embed_f16: B * (C0 + E) too large");
+    hipLaunchKernelGGL(time_embed_kernel, dim3((E + 63) / 64), dim3(256), lds, ctx->stream, t, B, C0, E, (const half_t*)W1, (const half_t*)b1,
+                       (const half_t*)W2, (const half_t*)b2, (const half_t*)add, ld_add, (half_t*)out, ld_out);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
 }
 int fie_clip_embed_f16(fie_ctx* ctx, const int32_t* ids, int B, int T, int C, const void* tok_table, const void* pos_table, void* out) {
     return clip_embed_t<half_t>(ctx, ids, B, T, C, tok_table, pos_table, out);

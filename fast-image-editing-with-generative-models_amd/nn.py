@@ -154,6 +154,9 @@ class _CondNet:
         self.conv_in = Conv3(ctx, sd, "conv_in", cin_pad=8)
         self.t1, self.t2 = Linear(ctx, sd, "time_embedding.linear_1", quant=False), Linear(ctx, sd, "time_embedding.linear_2", quant=False)
         self.a1, self.a2 = Linear(ctx, sd, "add_embedding.linear_1", quant=False), Linear(ctx, sd, "add_embedding.linear_2", quant=False)
+        # fp16 path: the per-step timestep embedding runs in ONE fused kernel (fie_time_embed_f16) on the plain weights
+        self.te = None if ctx.f32 else tuple(_dev(ctx, sd[k]) for k in ("time_embedding.linear_1.weight", "time_embedding.linear_1.bias",
+                                                                         "time_embedding.linear_2.weight", "time_embedding.linear_2.bias"))
         self.down = []
         for i in range(len(chans)):
             layers = []
@@ -213,6 +216,8 @@ class _CondNet:
         """silu(time_emb + add_emb) -> all resnets' time projections in one GEMM.  t_dev: f32 [B, 1] on device."""
         ctx = self.ctx
         ch0 = self.cfg["block_out_channels"][0]
+        if self.te is not None and t_dev.shape[0] <= 16:
+            return self.temb_proj(ctx, ctx.time_embed(t_dev, *self.te, add=self.add_emb))
         s = torch.empty((t_dev.shape[0], ch0), device=ctx.device, dtype=ctx.dtype)
         ctx.sinusoid(t_dev, ch0, s)
         # emb = time_emb + add_emb; resnets consume Linear(SiLU(emb)): add_emb rides in as a per-row bias so the

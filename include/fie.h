@@ -98,6 +98,14 @@ int fie_layernorm_f16(fie_ctx* ctx, const void* X, int64_t ldx, void* Y, int64_t
 int fie_sinusoid_f16(fie_ctx* ctx, const float* vals, int B, int nvals, int dim, void* out, int64_t ld_out,
                      int col0);
 
+/* ---- K7 fused: the whole per-step timestep path in ONE launch (sinusoid -> Linear -> SiLU -> Linear -> + text-time embedding ->
+ * the SiLU in front of every resnet's time projection).  Replaces Timesteps + TimestepEmbedding of embeddings.py and the
+ * `emb = emb + aug_emb` / `nonlinearity(temb)` steps of unet_2d_condition.py / resnet.py for the M = batch rows of one step.
+ *   t: f32 [B] on the device; W1 [E][C0], W2 [E][E] plain row-major f16 (NOT packed), b1, b2 [E]; add: [B][ld_add] f16 or NULL;
+ *   out[b, n] = silu(W2 silu(W1 [cos(t f) | sin(t f)] + b1) + b2 + add[b, n]).  B <= 16, C0 % 16 == 0, E % 8 == 0. */
+int fie_time_embed_f16(fie_ctx* ctx, const float* t, int B, int C0, int E, const void* W1, const void* b1, const void* W2,
+                       const void* b2, const void* add, int64_t ld_add, void* out, int64_t ld_out);
+
 /* ---- K12 token + position embedding gather (CLIPTextEmbeddings). ids: int32 [B*T] on device. */
 int fie_clip_embed_f16(fie_ctx* ctx, const int32_t* ids, int B, int T, int C, const void* tok_table,
                        const void* pos_table, void* out);
