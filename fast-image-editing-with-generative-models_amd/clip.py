@@ -35,13 +35,17 @@ class ClipText:
         self.final_ln = Norm(ctx, sd, "text_model.final_layer_norm")
         self.proj = Linear(ctx, None, None, w=sd["text_projection.weight"]) if cfg["projection_dim"] else None
         self.act = hip.ACT_QUICK_GELU if cfg["act"] == "quick_gelu" else hip.ACT_GELU
+        self.zero_row = torch.zeros((1, cfg["hidden"]), device=ctx.device, dtype=ctx.dtype)     # "position table" of the EOS-row gather
 
     def __call__(self, ids, eos_rows=None):
         """ids: int tensor [B, T] (host or device).  Returns (penultimate [B*T, C] f16, pooled [B, P] f16 or None)."""
         ctx, cfg = self.ctx, self.cfg
         b, t = ids.shape
         c, heads = cfg["hidden"], cfg["heads"]
-        x = ctx.clip_embed(ids.to(ctx.device, torch.int32).contiguous(), self.tok, self.pos)
+        ids_dev = ids.to(ctx.device, torch.int32).contiguous()
+        if ctx._keep is not None:
+            ctx._keep.append(ids_dev)             # (a converted copy: new token ids must then be written into ids_dev's source)
+        x = ctx.clip_embed(ids_dev, self.tok, self.pos)
         n_run = cfg["layers"] if self.proj is not None else cfg["layers"] - 1   # last layer only feeds the pooled output
         penult = None
         for i in range(n_run):
@@ -61,6 +65,11 @@ class ClipText:
             last = ctx.layernorm(x, self.final_ln.g, self.final_ln.b, cfg["eps"])
             if eos_rows is None:                                                  # first EOS (host index logic)
                 eos = eos_positions(ids.to("cpu"), cfg["eos_token_id"])
-                eos_rows = (torch.arange(b) * t + eos).to(ctx.device)
-            pooled = self.proj(ctx, last.index_select(0, eos_rows))
+                eos_rows = (torch.arange(b) * t + eos).to(ctx.device, torch.int32)
+            # EOS rows gathered by the embedding-gather kernel (table = the final-LN states, one "position" of zeros): no torch
+            # kernel inside the graph, so the whole encoder is a launch program (fie_clip_text_forward)
+            idx = eos_rows if eos_rows.dtype == torch.int32 else eos_rows.to(torch.int32)
+            if ctx._keep is not None:
+                ctx._keep.append(idx)             # a launch program reads the indices by raw pointer: keep a converted copy alive
+            pooled = self.proj(ctx, ctx.clip_embed(idx.view(-1, 1), last, self.zero_row))
         return penult, pooled

@@ -200,7 +200,7 @@ int launch_attn(fie_ctx* ctx, const AttnArgs& a, int B) {
         attr_set = true;
     }
     const dim3 grid((unsigned)((a.Tq + 64 * QF - 1) / (64 * QF)), (unsigned)a.H, (unsigned)B), block(256);
-    hipLaunchKernelGGL((attn_kernel<D, QF, KT>), grid, block, lds, ctx->stream, a);
+    fie_launch(ctx, (attn_kernel<D, QF, KT>), grid, block, lds, a);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -466,7 +466,7 @@ int launch_attn2(fie_ctx* ctx, const AttnArgs& a, int B) {
         attr_set = true;
     }
     const dim3 grid((unsigned)((a.Tq + 64 * QF - 1) / (64 * QF)), (unsigned)a.H, (unsigned)B), block(256);
-    hipLaunchKernelGGL((attn2_kernel<D, QF, KT>), grid, block, lds, ctx->stream, a);
+    fie_launch(ctx, (attn2_kernel<D, QF, KT>), grid, block, lds, a);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

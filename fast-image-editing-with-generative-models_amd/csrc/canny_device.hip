@@ -136,8 +136,7 @@ int fie_canny_rgb_device_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int 
     if (low > high) { int t = low; low = high; high = t; }
     uint8_t* map = (uint8_t*)workspace;
     int* flag = (int*)(map + (((size_t)H * W + 63) / 64) * 64);
-    hipLaunchKernelGGL(canny_nms_kernel, dim3((W + TX - 1) / TX, (H + TY - 1) / TY), dim3(TX, TY), 0, ctx->stream, rgb, H, W, low,
-                       high, map);
+    fie_launch(ctx, canny_nms_kernel, dim3((W + TX - 1) / TX, (H + TY - 1) / TY), dim3(TX, TY), 0, rgb, H, W, low, high, map);
     FIE_LAUNCH_CHECK();
     const dim3 hgrid((W + HT - 1) / HT, (H + HT - 1) / HT);
     int iters = 0;
@@ -145,8 +144,8 @@ int fie_canny_rgb_device_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int 
     for (;;) {
         int h = 0;
         if (hipMemsetAsync(flag, 0, sizeof(int), ctx->stream) != hipSuccess) { fie_set_error("fie_canny_rgb_device_u8: memset failed"); return FIE_EHIP; }
-        hipLaunchKernelGGL(canny_hyst_kernel, hgrid, dim3(256), 0, ctx->stream, map, H, W, flag);
-        hipLaunchKernelGGL(canny_hyst_kernel, hgrid, dim3(256), 0, ctx->stream, map, H, W, flag);
+        fie_launch(ctx, canny_hyst_kernel, hgrid, dim3(256), 0, map, H, W, flag);
+        fie_launch(ctx, canny_hyst_kernel, hgrid, dim3(256), 0, map, H, W, flag);
         FIE_LAUNCH_CHECK();
         if (hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
@@ -158,8 +157,7 @@ int fie_canny_rgb_device_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int 
         if (iters > max_iters) { fie_set_error("fie_canny_rgb_device_u8: hysteresis did not converge in %d passes", iters); return FIE_EHIP; }
     }
     const size_t n = (size_t)H * W;
-    hipLaunchKernelGGL(canny_out_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       map, n, edges_rgb);
+    fie_launch(ctx, canny_out_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, map, n, edges_rgb);
     FIE_LAUNCH_CHECK();
     if (iterations) *iterations = iters;
     return FIE_OK;

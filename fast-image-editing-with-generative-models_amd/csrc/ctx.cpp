@@ -1,6 +1,7 @@
 // Context + error plumbing of the C ABI (include/fie.h).
 #include <stdarg.h>
 #include <string.h>
+#include <iterator>
 #include "fie_internal.h"
 
 int fie_gemm_init(void);
@@ -59,6 +60,68 @@ int fie_ctx_create(int device, void* stream, fie_ctx** out) {
     return FIE_OK;
 }
 
+// ---- launch programs + graph-level entries (fie_unet_forward, fie_controlnet_forward, fie_vae_{encode,decode},
+// fie_clip_text_forward): the host walks a graph ONCE with its static device buffers while a program records every launch;
+// afterwards the named entry re-issues the whole graph from C++ (no Python, no shape logic, hipGraph-capturable like any launch).
+int fie_program_begin(fie_ctx* ctx, fie_program** out) {
+    FIE_REQUIRE(ctx && out, "fie_program_begin: NULL argument");
+    FIE_REQUIRE(ctx->recording == nullptr, "fie_program_begin: a program is already being recorded on this ctx");
+    *out = ctx->recording = new fie_program();
+    return FIE_OK;
+}
+
+int fie_program_end(fie_ctx* ctx) {
+    FIE_REQUIRE(ctx && ctx->recording, "fie_program_end: nothing is being recorded");
+    ctx->recording = nullptr;
+    return FIE_OK;
+}
+
+int fie_program_launches(const fie_program* p) { return p ? (int)p->recs.size() : -1; }
+
+int fie_program_run(fie_ctx* ctx, const fie_program* p) {
+    FIE_REQUIRE(ctx && p, "fie_program_run: NULL argument");
+    FIE_REQUIRE(ctx->recording != p, "fie_program_run: the program is still being recorded");
+    void* argv[64];
+    for (const fie_launch_rec& r : p->recs) {
+        FIE_REQUIRE(r.offs.size() <= 64, "fie_program_run: too many kernel arguments");
+        for (size_t i = 0; i < r.offs.size(); ++i) argv[i] = const_cast<unsigned char*>(r.blob.data()) + r.offs[i];
+        const hipError_t e = hipLaunchKernel(r.fn, r.grid, r.block, argv, r.lds, ctx->stream);
+        if (e != hipSuccess) {
+            fie_set_error("fie_program_run: launch failed: %s", hipGetErrorString(e));
+            return FIE_EHIP;
+        }
+        if (ctx->recording) ctx->recording->recs.push_back(r);       // programs nest: running one while recording another copies it in
+    }
+    return FIE_OK;
+}
+
+int fie_program_destroy(fie_ctx* ctx, fie_program* p) {
+    if (ctx)
+        for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();)
+            it = it->second == p ? ctx->graphs.erase(it) : std::next(it);
+    delete p;
+    return FIE_OK;
+}
+
+int fie_graph_register(fie_ctx* ctx, const char* name, fie_program* p) {
+    FIE_REQUIRE(ctx && name && p, "fie_graph_register: NULL argument");
+    ctx->graphs[name] = p;
+    return FIE_OK;
+}
+
+static int run_graph(fie_ctx* ctx, const char* name) {
+    FIE_REQUIRE(ctx != nullptr, "%s: ctx is NULL", name);
+    auto it = ctx->graphs.find(name);
+    FIE_REQUIRE(it != ctx->graphs.end(), "%s: no program registered under this name (fie_graph_register)", name);
+    return fie_program_run(ctx, it->second);
+}
+
+int fie_unet_forward(fie_ctx* ctx) { return run_graph(ctx, "unet_forward"); }
+int fie_controlnet_forward(fie_ctx* ctx) { return run_graph(ctx, "controlnet_forward"); }
+int fie_vae_encode(fie_ctx* ctx) { return run_graph(ctx, "vae_encode"); }
+int fie_vae_decode(fie_ctx* ctx) { return run_graph(ctx, "vae_decode"); }
+int fie_clip_text_forward(fie_ctx* ctx) { return run_graph(ctx, "clip_text_forward"); }
+
 int fie_ctx_set_stream(fie_ctx* ctx, void* stream) {
     FIE_REQUIRE(ctx != nullptr, "fie_ctx_set_stream: ctx is NULL");
     ctx->stream = (hipStream_t)stream;
@@ -66,7 +129,7 @@ int fie_ctx_set_stream(fie_ctx* ctx, void* stream) {
 }
 
 int fie_ctx_destroy(fie_ctx* ctx) {
-    delete ctx;
+    delete ctx;                       // registered programs are owned by the caller (fie_program_destroy)
     return FIE_OK;
 }
 

@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void softmax_rows_f32_kernel(float* S, int64_t
 
 int launch32(fie_ctx* ctx, G32& a, int mode, int batch) {
     const dim3 grid((unsigned)((a.N + T - 1) / T), (unsigned)((a.M + T - 1) / T), (unsigned)batch);
-    if (mode == 1) hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(gemm_f32_kernel<0>, grid, dim3(256), 0, ctx->stream, a);
+    if (mode == 1) fie_launch(ctx, gemm_f32_kernel<1>, grid, dim3(256), 0, a);
+    else fie_launch(ctx, gemm_f32_kernel<0>, grid, dim3(256), 0, a);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -217,7 +217,7 @@ int fie_conv3x3_nhwc_f32(fie_ctx* ctx, const float* X, int B, int H, int W, int 
 
 int fie_softmax_rows_f32(fie_ctx* ctx, float* S, int64_t rows, int cols, int64_t ld, float scale, int causal, int tq) {
     FIE_REQUIRE(ctx && S && rows > 0 && cols > 0 && ld >= cols && tq > 0, "fie_softmax_rows_f32: bad argument");
-    hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, S, rows, cols, ld, scale, causal, tq);
+    fie_launch(ctx, softmax_rows_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S, rows, cols, ld, scale, causal, tq);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

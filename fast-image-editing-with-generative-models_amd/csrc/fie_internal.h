@@ -3,6 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
 #include "../../include/fie.h"
 
 typedef _Float16 half_t;
@@ -12,6 +18,21 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- launch programs (include/fie.h, fie_program_*): every kernel launch of the library goes through fie_launch(); while a
+// program is being recorded the launch (kernel, grid, block, dynamic LDS, argument bytes) is appended to it, and
+// fie_program_run() re-issues the list with hipLaunchKernel -- the graph-level entries (fie_unet_forward, ...) run such lists
+// without any host-side shape logic.
+struct fie_launch_rec {
+    const void* fn;
+    dim3 grid, block;
+    unsigned lds;
+    std::vector<unsigned char> blob;      // argument values, naturally aligned
+    std::vector<unsigned> offs;           // offset of each argument in blob
+};
+struct fie_program {
+    std::vector<fie_launch_rec> recs;
+};
 
 struct fie_tile_override { int mode, M, N, K, code; };   // tuning hook: per-shape GEMM / conv tile code (mode 0 GEMM, 1 conv)
 
@@ -25,7 +46,32 @@ struct fie_ctx {
     int n_overrides = 0;
     fie_tile_override overrides[32];
     char last_kernel[96] = "";
+    fie_program* recording = nullptr;                 // launches are appended here while set (fie_program_begin / _end)
+    std::map<std::string, fie_program*> graphs;       // fie_graph_register: "unet_forward", "vae_decode", ...
 };
+
+template <typename T>
+inline void fie_pack_arg(fie_launch_rec& r, const T& v) {
+    size_t off = (r.blob.size() + alignof(T) - 1) / alignof(T) * alignof(T);
+    r.blob.resize(off + sizeof(T));
+    memcpy(r.blob.data() + off, &v, sizeof(T));
+    r.offs.push_back((unsigned)off);
+}
+
+// The one launch point of the library: asynchronous on the ctx stream; recorded when a program is open.
+template <typename... KArgs, typename... Args>
+inline void fie_launch(fie_ctx* ctx, void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, Args&&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count");
+    std::tuple<KArgs...> vals(static_cast<KArgs>(args)...);
+    std::apply([&](const KArgs&... a) { hipLaunchKernelGGL(kernel, grid, block, lds, ctx->stream, a...); }, vals);
+    if (ctx->recording) {
+        fie_launch_rec r;
+        r.fn = reinterpret_cast<const void*>(kernel);
+        r.grid = grid; r.block = block; r.lds = lds;
+        std::apply([&](const KArgs&... a) { (fie_pack_arg(r, a), ...); }, vals);
+        ctx->recording->recs.push_back(std::move(r));
+    }
+}
 
 void fie_set_error(const char* fmt, ...);
 

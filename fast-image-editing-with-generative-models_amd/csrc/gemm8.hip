@@ -269,10 +269,10 @@ int fie_gemm8_init(void) {
 
 int fie_launch_gemm8(fie_ctx* ctx, const GemmArgs& a, int conv, int split) {
     const dim3 grid((unsigned)(a.nbm * a.nbn));
-    if (conv && split) hipLaunchKernelGGL((gemm8_kernel<2, 1>), grid, dim3(512), kLds8, ctx->stream, a);
-    else if (conv) hipLaunchKernelGGL((gemm8_kernel<2, 0>), grid, dim3(512), kLds8, ctx->stream, a);
-    else if (split) hipLaunchKernelGGL((gemm8_kernel<0, 1>), grid, dim3(512), kLds8, ctx->stream, a);
-    else hipLaunchKernelGGL((gemm8_kernel<0, 0>), grid, dim3(512), kLds8, ctx->stream, a);
+    if (conv && split) fie_launch(ctx, (gemm8_kernel<2, 1>), grid, dim3(512), kLds8, a);
+    else if (conv) fie_launch(ctx, (gemm8_kernel<2, 0>), grid, dim3(512), kLds8, a);
+    else if (split) fie_launch(ctx, (gemm8_kernel<0, 1>), grid, dim3(512), kLds8, a);
+    else fie_launch(ctx, (gemm8_kernel<0, 0>), grid, dim3(512), kLds8, a);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

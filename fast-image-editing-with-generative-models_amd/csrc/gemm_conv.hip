@@ -314,7 +314,7 @@ hipError_t ring_attr() {
 template <int BM, int BN, int ST, int MODE, int NW>
 void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
     constexpr int lds = ring_lds<BM, BN, ST, NW>();
-    hipLaunchKernelGGL((gemm3_kernel<BM, BN, ST, MODE, NW>), grid, dim3(NW * 64), lds, ctx->stream, a);
+    fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW>), grid, dim3(NW * 64), lds, a);
 }
 
 // ---- tile codes (also the values fie_debug_force_tile / fie_debug_tile_override take)
@@ -393,9 +393,9 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     const dim3 grid((unsigned)(a.nbm * a.nbn)), block(256);
     constexpr int M3 = MODE == 1 ? 2 : 0;
     switch (code) {
-        case 1: hipLaunchKernelGGL((gemm_kernel<128, 128, MODE>), grid, block, 0, ctx->stream, a); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<128, 64, MODE>), grid, block, 0, ctx->stream, a); break;
-        case 3: hipLaunchKernelGGL((gemm_kernel<64, 64, MODE>), grid, block, 0, ctx->stream, a); break;
+        case 1: fie_launch(ctx, (gemm_kernel<128, 128, MODE>), grid, block, 0, a); break;
+        case 2: fie_launch(ctx, (gemm_kernel<128, 64, MODE>), grid, block, 0, a); break;
+        case 3: fie_launch(ctx, (gemm_kernel<64, 64, MODE>), grid, block, 0, a); break;
         case 41: launch_ring<128, 128, 3, M3, 4>(ctx, a, grid); break;
         case 42: launch_ring<128, 64, 3, M3, 4>(ctx, a, grid); break;
         case 43: launch_ring<64, 64, 3, M3, 4>(ctx, a, grid); break;
@@ -589,8 +589,7 @@ int fie_pack_rows_f16(fie_ctx* ctx, const void* src, int64_t ld_src, int N, int 
     FIE_REQUIRE(ctx && src && dst, "fie_pack_rows_f16: NULL argument");
     FIE_REQUIRE(N > 0 && K > 0 && Npad >= N && ldw >= K, "fie_pack_rows_f16: bad shape");
     FIE_REQUIRE(!interleave2 || N % 2 == 0, "fie_pack_rows_f16: interleave2 needs even N");
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const half_t*)src, ld_src, N, K,
-                       (half_t*)dst, ldw, Npad, interleave2);
+    fie_launch(ctx, pack_rows_kernel, dim3(1024), dim3(256), 0, (const half_t*)src, ld_src, N, K, (half_t*)dst, ldw, Npad, interleave2);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -599,8 +598,7 @@ int fie_pack_conv3x3_f16(fie_ctx* ctx, const void* src_oihw, int Cout, int Cin, 
                          int Npad) {
     FIE_REQUIRE(ctx && src_oihw && dst, "fie_pack_conv3x3_f16: NULL argument");
     FIE_REQUIRE(cin_pad >= Cin && cin_pad % 8 == 0 && ldw >= 9 * cin_pad && Npad >= Cout, "fie_pack_conv3x3_f16: bad shape");
-    hipLaunchKernelGGL(pack_conv_kernel, dim3(1024), dim3(256), 0, ctx->stream, (const half_t*)src_oihw, Cout, Cin,
-                       cin_pad, (half_t*)dst, ldw, Npad);
+    fie_launch(ctx, pack_conv_kernel, dim3(1024), dim3(256), 0, (const half_t*)src_oihw, Cout, Cin, cin_pad, (half_t*)dst, ldw, Npad);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

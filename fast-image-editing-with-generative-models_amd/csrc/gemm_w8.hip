@@ -226,8 +226,8 @@ int fie_gemm_w8_init(void) {
 template <int BM, int BN, int NW>
 static void launch_w8(fie_ctx* ctx, const GemmArgs& a, int conv, dim3 grid) {
     constexpr int lds = w8_lds<BM, BN, 3>();
-    if (conv) hipLaunchKernelGGL((gemm3w8_kernel<BM, BN, 3, 2, NW>), grid, dim3(NW * 64), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((gemm3w8_kernel<BM, BN, 3, 0, NW>), grid, dim3(NW * 64), lds, ctx->stream, a);
+    if (conv) fie_launch(ctx, (gemm3w8_kernel<BM, BN, 3, 2, NW>), grid, dim3(NW * 64), lds, a);
+    else fie_launch(ctx, (gemm3w8_kernel<BM, BN, 3, 0, NW>), grid, dim3(NW * 64), lds, a);
 }
 
 // code: 62 (256x128, 8 waves), 42 (128x64), 43 (64x64)
@@ -247,8 +247,7 @@ int fie_pack_rows_f8(fie_ctx* ctx, const void* src, int64_t ld_src, int N, int K
     FIE_REQUIRE(ctx && src && dst && scales, "fie_pack_rows_f8: NULL argument");
     FIE_REQUIRE(N > 0 && K > 0 && Npad >= N && ldw >= K && ldw % 64 == 0, "fie_pack_rows_f8: bad shape");
     FIE_REQUIRE(!interleave2 || N % 2 == 0, "fie_pack_rows_f8: interleave2 needs even N");
-    hipLaunchKernelGGL((pack_f8_kernel<false>), dim3(Npad), dim3(256), 0, ctx->stream, (const half_t*)src, ld_src, N, K, 0, 0,
-                       (unsigned char*)dst, ldw, scales, interleave2);
+    fie_launch(ctx, (pack_f8_kernel<false>), dim3(Npad), dim3(256), 0, (const half_t*)src, ld_src, N, K, 0, 0, (unsigned char*)dst, ldw, scales, interleave2);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -257,8 +256,7 @@ int fie_pack_conv3x3_f8(fie_ctx* ctx, const void* src_oihw, int Cout, int Cin, i
                         float* scales) {
     FIE_REQUIRE(ctx && src_oihw && dst && scales, "fie_pack_conv3x3_f8: NULL argument");
     FIE_REQUIRE(cin_pad >= Cin && cin_pad % 8 == 0 && ldw >= 9 * cin_pad && ldw % 64 == 0 && Npad >= Cout, "fie_pack_conv3x3_f8: bad shape");
-    hipLaunchKernelGGL((pack_f8_kernel<true>), dim3(Npad), dim3(256), 0, ctx->stream, (const half_t*)src_oihw, 0, Cout, 9 * cin_pad, Cin,
-                       cin_pad, (unsigned char*)dst, ldw, scales, 0);
+    fie_launch(ctx, (pack_f8_kernel<true>), dim3(Npad), dim3(256), 0, (const half_t*)src_oihw, 0, Cout, 9 * cin_pad, Cin, cin_pad, (unsigned char*)dst, ldw, scales, 0);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

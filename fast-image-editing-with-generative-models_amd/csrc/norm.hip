@@ -280,11 +280,11 @@ bool gn_onepass(fie_ctx* ctx, const GnArgsT<T>& p, int B) {
     const int npv = p.cg / V, rstep = GN1_THREADS / npv;
     const int64_t nv = (p.rows + rstep - 1) / rstep;
     const dim3 grid((unsigned)p.G, (unsigned)B);
-    if (V == 8 && nv <= 5) hipLaunchKernelGGL((gn_onepass_kernel<8, 5, T>), grid, dim3(GN1_THREADS), 0, ctx->stream, p);
-    else if (V == 8 && nv <= 10) hipLaunchKernelGGL((gn_onepass_kernel<8, 10, T>), grid, dim3(GN1_THREADS), 0, ctx->stream, p);
+    if (V == 8 && nv <= 5) fie_launch(ctx, (gn_onepass_kernel<8, 5, T>), grid, dim3(GN1_THREADS), 0, p);
+    else if (V == 8 && nv <= 10) fie_launch(ctx, (gn_onepass_kernel<8, 10, T>), grid, dim3(GN1_THREADS), 0, p);
     // V = 4 at rows = 4096 (64x64 latents, 21 vectors) measured SLOWER than the three-kernel path (28.5 vs 22.0 us: 40-byte
     // slices at a 1280-byte stride), so the bound stays at 20
-    else if (V == 4 && nv <= 20) hipLaunchKernelGGL((gn_onepass_kernel<4, 20, T>), grid, dim3(GN1_THREADS), 0, ctx->stream, p);
+    else if (V == 4 && nv <= 20) fie_launch(ctx, (gn_onepass_kernel<4, 20, T>), grid, dim3(GN1_THREADS), 0, p);
     else return false;
     return true;
 }
@@ -383,9 +383,9 @@ int groupnorm_t(const char* who, fie_ctx* ctx, const void* X1, int C1, const voi
     p.partial = (float*)workspace;
     p.stats = p.partial + (int64_t)B * GN_MAX_CHUNKS * groups * 2;
     const dim3 grid((unsigned)p.nchunks, (unsigned)B, (unsigned)csplit);
-    hipLaunchKernelGGL(gn_partial_kernel<T>, grid, dim3(GN_THREADS), 0, ctx->stream, p);
-    hipLaunchKernelGGL(gn_finalize_kernel<T>, dim3((B * groups + 3) / 4), dim3(256), 0, ctx->stream, p, B);
-    hipLaunchKernelGGL(gn_apply_kernel<T>, grid, dim3(GN_THREADS), 0, ctx->stream, p);
+    fie_launch(ctx, gn_partial_kernel<T>, grid, dim3(GN_THREADS), 0, p);
+    fie_launch(ctx, gn_finalize_kernel<T>, dim3((B * groups + 3) / 4), dim3(256), 0, p, B);
+    fie_launch(ctx, gn_apply_kernel<T>, grid, dim3(GN_THREADS), 0, p);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -396,8 +396,7 @@ int layernorm_t(const char* who, fie_ctx* ctx, const void* X, int64_t ldx, void*
     FIE_REQUIRE(ctx && X && Y && gamma && beta, "%s: NULL argument", who);
     FIE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "%s: C=%d unsupported", who, C);
     FIE_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "%s: bad strides", who);
-    hipLaunchKernelGGL(ln_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const T*)X, ldx, (T*)Y, ldy, rows, C,
-                       (const T*)gamma, (const T*)beta, eps);
+    fie_launch(ctx, ln_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (const T*)X, ldx, (T*)Y, ldy, rows, C, (const T*)gamma, (const T*)beta, eps);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

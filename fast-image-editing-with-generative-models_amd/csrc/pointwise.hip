@@ -206,7 +206,7 @@ int sinusoid_t(fie_ctx* ctx, const float* vals, int B, int nvals, int dim, void*
     FIE_REQUIRE(ctx && vals && out, "fie_sinusoid: NULL argument");
     FIE_REQUIRE(B > 0 && nvals > 0 && dim > 0 && dim % 2 == 0 && ld_out >= col0 + nvals * dim, "fie_sinusoid: bad shape");
     const int total = B * nvals * (dim / 2);
-    hipLaunchKernelGGL(sinusoid_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, vals, B, nvals, dim, (T*)out, ld_out, col0);
+    fie_launch(ctx, sinusoid_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, vals, B, nvals, dim, (T*)out, ld_out, col0);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -215,8 +215,7 @@ template <typename T>
 int clip_embed_t(fie_ctx* ctx, const int32_t* ids, int B, int Tn, int C, const void* tok, const void* pos, void* out) {
     FIE_REQUIRE(ctx && ids && tok && pos && out, "fie_clip_embed: NULL argument");
     FIE_REQUIRE(B > 0 && Tn > 0 && C > 0 && C % 8 == 0, "fie_clip_embed: bad shape");
-    hipLaunchKernelGGL(clip_embed_kernel<T>, dim3(grid_for((int64_t)B * Tn * C / 8)), dim3(256), 0, ctx->stream, ids, B * Tn, Tn, C,
-                       (const T*)tok, (const T*)pos, (T*)out);
+    fie_launch(ctx, clip_embed_kernel<T>, dim3(grid_for((int64_t)B * Tn * C / 8)), dim3(256), 0, ids, B * Tn, Tn, C, (const T*)tok, (const T*)pos, (T*)out);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -225,7 +224,7 @@ template <typename T>
 int pixels_in_t(fie_ctx* ctx, const uint8_t* src, int H, int W, int normalize, void* dst, int copies) {
     FIE_REQUIRE(ctx && src && dst && H > 0 && W > 0 && copies > 0, "fie_pixels_in: bad argument");
     const int64_t n = (int64_t)H * W;
-    hipLaunchKernelGGL(pixels_in_kernel<T>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, src, n, normalize, (T*)dst, copies);
+    fie_launch(ctx, pixels_in_kernel<T>, dim3(grid_for(n)), dim3(256), 0, src, n, normalize, (T*)dst, copies);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -234,7 +233,7 @@ template <typename T>
 int pixels_out_t(fie_ctx* ctx, const void* src, int64_t ld_in, int H, int W, uint8_t* dst) {
     FIE_REQUIRE(ctx && src && dst && H > 0 && W > 0 && ld_in >= 3, "fie_pixels_out: bad argument");
     const int64_t n = (int64_t)H * W;
-    hipLaunchKernelGGL(pixels_out_kernel<T>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const T*)src, ld_in, n, dst);
+    fie_launch(ctx, pixels_out_kernel<T>, dim3(grid_for(n)), dim3(256), 0, (const T*)src, ld_in, n, dst);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -243,8 +242,7 @@ template <typename T>
 int latent_prep_t(fie_ctx* ctx, const void* moments, const float* eps_post, const float* noise, int64_t HW, float sf, float sqrt_ab,
                   float sqrt_1mab, float* latents_out, void* model_in, int copies) {
     FIE_REQUIRE(ctx && moments && eps_post && noise && latents_out && model_in && HW > 0 && copies > 0, "fie_latent_prep: bad argument");
-    hipLaunchKernelGGL(latent_prep_kernel<T>, dim3(grid_for(HW)), dim3(256), 0, ctx->stream, (const T*)moments, eps_post, noise, HW, sf,
-                       sqrt_ab, sqrt_1mab, latents_out, (T*)model_in, copies);
+    fie_launch(ctx, latent_prep_kernel<T>, dim3(grid_for(HW)), dim3(256), 0, (const T*)moments, eps_post, noise, HW, sf, sqrt_ab, sqrt_1mab, latents_out, (T*)model_in, copies);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -259,7 +257,7 @@ int lcm_step_t(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, float guid
     FIE_REQUIRE(sqrt_ab_t > 0.f, "fie_lcm_step: sqrt(alpha_bar_t) must be positive");
     LcmArgs<T> p = {(const T*)eps, ld_eps, nb, guidance, latents, noise, HW, sqrt_ab_t, sqrt_1mab_t, c_skip, c_out,
                     sqrt_ab_prev, sqrt_1mab_prev, (T*)model_in, copies, inv_scaling, (T*)decode_in};
-    hipLaunchKernelGGL(lcm_step_kernel<T>, dim3(grid_for(HW)), dim3(256), 0, ctx->stream, p);
+    fie_launch(ctx, lcm_step_kernel<T>, dim3(grid_for(HW)), dim3(256), 0, p);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -281,8 +279,7 @@ int fie_time_embed_f16(fie_ctx* ctx, const float* t, int B, int C0, int E, const
                 "fie_time_embed_f16: bad shape (B <= %d, C0 %% 16 == 0, E %% 8 == 0)", kTeMaxB);
     const int lds = B * (C0 + E) * (int)sizeof(half_t);
     FIE_REQUIRE(lds <= 64 * 1024, "fie_time_embed_f16: B * (C0 + E) too large");
-    hipLaunchKernelGGL(time_embed_kernel, dim3((E + 63) / 64), dim3(256), lds, ctx->stream, t, B, C0, E, (const half_t*)W1, (const half_t*)b1,
-                       (const half_t*)W2, (const half_t*)b2, (const half_t*)add, ld_add, (half_t*)out, ld_out);
+    fie_launch(ctx, time_embed_kernel, dim3((E + 63) / 64), dim3(256), lds, t, B, C0, E, (const half_t*)W1, (const half_t*)b1, (const half_t*)W2, (const half_t*)b2, (const half_t*)add, ld_add, (half_t*)out, ld_out);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

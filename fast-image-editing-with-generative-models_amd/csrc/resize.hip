@@ -63,12 +63,12 @@ extern "C" int fie_resize_rgb_u8(fie_ctx* ctx, const uint8_t* src, int H, int W,
     const uint8_t* vin = src;
     if (W != OW) {                         // horizontal pass first, as Pillow does
         uint8_t* hout = H == OH ? dst : tmp;
-        hipLaunchKernelGGL(resize_h_kernel, dim3((OW + 255) / 256, H), dim3(256), 0, ctx->stream, src, H, W, OW, kx, bx, ksx, hout);
+        fie_launch(ctx, resize_h_kernel, dim3((OW + 255) / 256, H), dim3(256), 0, src, H, W, OW, kx, bx, ksx, hout);
         FIE_LAUNCH_CHECK();
         vin = hout;
     }
     if (H != OH) {
-        hipLaunchKernelGGL(resize_v_kernel, dim3((OW + 255) / 256, OH), dim3(256), 0, ctx->stream, vin, OW, OH, ky, by, ksy, dst);
+        fie_launch(ctx, resize_v_kernel, dim3((OW + 255) / 256, OH), dim3(256), 0, vin, OW, OH, ky, by, ksy, dst);
         FIE_LAUNCH_CHECK();
     }
     if (W == OW && H == OH) FIE_REQUIRE(hipMemcpyAsync(dst, src, (size_t)H * W * 3, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess,

@@ -24,6 +24,17 @@ SIGNATURES = {
     "fie_ctx_create": [_I, _P, _c.POINTER(_P)],
     "fie_ctx_set_stream": [_P, _P],
     "fie_ctx_destroy": [_P],
+    "fie_program_begin": [_P, _c.POINTER(_P)],
+    "fie_program_end": [_P],
+    "fie_program_launches": [_P],
+    "fie_program_run": [_P, _P],
+    "fie_program_destroy": [_P, _P],
+    "fie_graph_register": [_P, _c.c_char_p, _P],
+    "fie_unet_forward": [_P],
+    "fie_controlnet_forward": [_P],
+    "fie_vae_encode": [_P],
+    "fie_vae_decode": [_P],
+    "fie_clip_text_forward": [_P],
     "fie_gemm_f16": [_P, _P, _L, _I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _P, _L, _F, _I],
     "fie_conv3x3_nhwc_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P, _P, _L, _P, _L, _F, _I],
     "fie_pack_rows_f8": [_P, _P, _L, _I, _I, _P, _L, _I, _P, _I],
@@ -115,6 +126,35 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+GRAPH_NAMES = ("unet_forward", "controlnet_forward", "vae_encode", "vae_decode", "clip_text_forward")
+
+
+class Program:
+    """A recorded launch program (include/fie.h, fie_program_*).  `keep` holds every tensor the op wrappers allocated while it
+    was recorded: the program references their memory by raw pointer."""
+
+    def __init__(self, ctx):
+        self.ctx, self.h, self.keep, self.outputs = ctx, _P(), [], None
+
+    def __len__(self):
+        return lib().fie_program_launches(self.h)
+
+    def run(self):
+        self.ctx.sync_stream()
+        _chk(lib().fie_program_run(self.ctx.h, self.h))
+        return self.outputs
+
+    def register(self, name):
+        """Bind to one of the graph-level C entries (fie_unet_forward, ...); `run_named(name)` then calls THAT entry."""
+        assert name in GRAPH_NAMES, name
+        _chk(lib().fie_graph_register(self.ctx.h, name.encode(), self.h))
+
+    def close(self):
+        if self.h:
+            lib().fie_program_destroy(self.ctx.h, self.h)
+            self.h = _P()
+
+
 class W8:
     """A packed fp8 (e4m3) weight: bytes [Npad, Kpad] + one fp32 dequantisation scale per output channel (include/fie.h,
     fie_pack_*_f8).  `stride(0)` mirrors the packed fp16 tensors so call sites stay the same."""
@@ -147,6 +187,7 @@ class Context:
         self._gn_ws = {}
         self._resize_tables = {}       # (in, out) -> (taps, bounds, ksize) of the LANCZOS resample, on the device
         self.ws_tag = 0
+        self._keep = None              # list collecting the tensors allocated while a program is being recorded (Context.record)
         self.w8 = False                # while True, pack_linear / pack_conv3x3 quantise eligible weights to fp8 e4m3 (see W8)
 
     def sync_stream(self):
@@ -154,6 +195,37 @@ class Context:
         if s != self._stream:
             _chk(lib().fie_ctx_set_stream(self.h, s))
             self._stream = s
+
+    # ------------------------------------------------------------------ launch programs / graph-level entries
+    def record(self):
+        """Context manager: `with ctx.record() as prog: out = model(...)` executes the ops as usual AND records every launch into
+        `prog`.  Works on whatever torch stream is current; tensors allocated by the op wrappers meanwhile stay referenced by
+        `prog.keep` (torch must not hand their memory to anybody else while the program lives)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            prog = Program(self)
+            self.sync_stream()
+            _chk(lib().fie_program_begin(self.h, ctypes.byref(prog.h)))
+            self._keep = prog.keep
+            try:
+                yield prog
+            finally:
+                self._keep = None
+                _chk(lib().fie_program_end(self.h))
+        return cm()
+
+    def run_named(self, name):
+        """Run the program registered under `name` through its C-ABI graph entry (fie_unet_forward, fie_vae_decode, ...)."""
+        self.sync_stream()
+        _chk(getattr(lib(), "fie_" + name)(self.h))
+
+    def _alloc(self, shape, dtype=None, zero=False):
+        t = (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=dtype or self.dtype)
+        if self._keep is not None:
+            self._keep.append(t)
+        return t
 
     # ------------------------------------------------------------------ tuning / test hooks (per ctx)
     def force_tile(self, code):
@@ -229,7 +301,7 @@ class Context:
             assert k == ktot
         nout = n // 2 if act == ACT_GEGLU else n
         if out is None:
-            out = torch.empty((m, nout), device=a.device, dtype=self.dtype)
+            out = self._alloc((m, nout))
         assert a.stride(1) == 1 and out.stride(1) == 1
         if self.f32:
             _chk(lib().fie_gemm_f32(self.h, _p(a), a.stride(0), k1, _p(a2), a2.stride(0) if a2 is not None else 0, _p(wp),
@@ -260,7 +332,7 @@ class Context:
         oh, ow = (hin + pads - 3) // stride + 1, (win + pads - 3) // stride + 1
         ldc = ldc or cout
         if out is None:
-            out = (torch.zeros if ldc != cout else torch.empty)((b, oh, ow, ldc), device=x.device, dtype=self.dtype)
+            out = self._alloc((b, oh, ow, ldc), zero=ldc != cout)
         if isinstance(wp, W8):
             _chk(lib().fie_conv3x3_w8_nhwc_f16(self.h, _p(x), b, h, w, cin, int(upsample), stride, pad_mode, _p(wp.q), wp.stride(0),
                                                _p(wp.scale), _p(out), out.stride(2), cout, _p(bias), _p(rowbias),
@@ -278,11 +350,11 @@ class Context:
         """q: [B*Tq, >=H*D] view (row stride free); k, v: [B*Tk, ...]; returns [B*Tq, H*D]."""
         self.sync_stream()
         if out is None:
-            out = torch.empty((batch * tq, heads * head_dim), device=q.device, dtype=self.dtype)
+            out = self._alloc((batch * tq, heads * head_dim))
         scale = scale if scale is not None else head_dim ** -0.5
         if self.f32:
             # S = Q K^T (batched over image x head) -> row softmax -> O = P V; the fp32 scores are simply materialised
-            s_ = torch.empty((batch * heads, tq, tk), device=q.device, dtype=torch.float32)
+            s_ = self._alloc((batch * heads, tq, tk), torch.float32)
             d = head_dim
             _chk(lib().fie_gemm_f32(self.h, _p(q), q.stride(0), d, None, 0, _p(k), k.stride(0), 0, _p(s_), tk, tq, tk, d, None, None, 0,
                                     0, None, 0, 1.0, ACT_NONE, batch, heads, tq * q.stride(0), d, tk * k.stride(0), d,
@@ -303,12 +375,14 @@ class Context:
         c2 = x2.shape[-1] if x2 is not None else 0
         assert x1.is_contiguous() and (x2 is None or x2.is_contiguous())
         if out is None:
-            out = torch.empty(x1.shape[:-1] + (c1 + c2,), device=x1.device, dtype=self.dtype)
+            out = self._alloc(x1.shape[:-1] + (c1 + c2,))
         need = lib().fie_groupnorm_workspace_bytes(b, rows, groups)
         key = (self._stream, self.ws_tag)            # one scratch buffer per stream (and per in-flight graph slot)
         ws = self._gn_ws.get(key)
         if ws is None or ws.numel() < need:
             ws = self._gn_ws[key] = torch.empty(need, device=self.device, dtype=torch.uint8)
+        if self._keep is not None:
+            self._keep.append(ws)
         _chk((lib().fie_groupnorm_nhwc_f32 if self.f32 else lib().fie_groupnorm_nhwc_f16)(self.h, _p(x1), c1, _p(x2), c2, _p(out), b, rows, groups, _p(gamma),
                                           _p(beta), float(eps), int(silu), _p(ws)))
         return out
@@ -317,7 +391,7 @@ class Context:
         self.sync_stream()
         rows, c = x.shape
         if out is None:
-            out = torch.empty((rows, c), device=x.device, dtype=self.dtype)
+            out = self._alloc((rows, c))
         _chk((lib().fie_layernorm_f32 if self.f32 else lib().fie_layernorm_f16)(self.h, _p(x), x.stride(0), _p(out), out.stride(0), rows, c, _p(gamma), _p(beta),
                                      float(eps)))
         return out
@@ -333,7 +407,7 @@ class Context:
         """K7 fused: silu(W2 silu(W1 sinusoid(t) + b1) + b2 + add) for the B rows of one step; w1 [E, C0], w2 [E, E] plain f16."""
         self.sync_stream()
         b, (e, c0) = t.numel(), w1.shape
-        out = torch.empty((b, e), device=self.device, dtype=torch.float16)
+        out = self._alloc((b, e), torch.float16)
         _chk(lib().fie_time_embed_f16(self.h, _p(t), b, c0, e, _p(w1), _p(b1), _p(w2), _p(b2), _p(add),
                                       add.stride(0) if add is not None else 0, _p(out), out.stride(0)))
         return out
@@ -342,21 +416,21 @@ class Context:
         self.sync_stream()
         b, t = ids.shape
         c = tok.shape[1]
-        out = torch.empty((b * t, c), device=tok.device, dtype=self.dtype)
+        out = self._alloc((b * t, c))
         _chk((lib().fie_clip_embed_f32 if self.f32 else lib().fie_clip_embed_f16)(self.h, _p(ids), b, t, c, _p(tok), _p(pos), _p(out)))
         return out
 
     def pixels_in(self, u8_hwc, normalize, copies=1):
         self.sync_stream()
         h, w, _ = u8_hwc.shape
-        out = torch.empty((copies, h, w, 8), device=u8_hwc.device, dtype=self.dtype)
+        out = self._alloc((copies, h, w, 8))
         _chk((lib().fie_pixels_in_u8_f32 if self.f32 else lib().fie_pixels_in_u8_f16)(self.h, _p(u8_hwc), h, w, int(normalize), _p(out), copies))
         return out
 
     def pixels_out(self, x_nhwc):
         self.sync_stream()
         _, h, w, ld = x_nhwc.shape
-        out = torch.empty((h, w, 3), device=x_nhwc.device, dtype=torch.uint8)
+        out = self._alloc((h, w, 3), torch.uint8)
         _chk((lib().fie_pixels_out_f32_u8 if self.f32 else lib().fie_pixels_out_f16_u8)(self.h, _p(x_nhwc), ld, h, w, _p(out)))
         return out
 

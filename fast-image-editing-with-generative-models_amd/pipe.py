@@ -133,7 +133,7 @@ class HipImg2ImgPipeline:
         eos = eos_positions(ids_g, self.cfgs["clip_g"]["eos_token_id"])                 # pooled-token column per row
         return dict(
             ids_l=self.tok_l(texts).to(dev, torch.int32), ids_g=ids_g.to(dev, torch.int32),
-            eos_rows=(torch.arange(nb) * ids_g.shape[1] + eos).to(dev),
+            eos_rows=(torch.arange(nb) * ids_g.shape[1] + eos).to(dev, torch.int32),
             img_u8=u8(image), ctl_u8=u8(control_image), hw=(h, w), steps=steps, nb=nb,
             guidance=float(guidance_scale), cn_scale=float(controlnet_conditioning_scale),
             time_ids=torch.tensor([[h, w, 0, 0, h, w]], dtype=torch.float32).repeat(nb, 1).to(dev),

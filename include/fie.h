@@ -46,6 +46,31 @@ int fie_ctx_create(int device, void* stream, fie_ctx** out);
 int fie_ctx_set_stream(fie_ctx* ctx, void* stream);
 int fie_ctx_destroy(fie_ctx* ctx);
 
+/* ---- Graph-level entries: the upstream calls they replace are the model forwards inside the diffusers pipeline call
+ * at /root/reference/src/pipeline.py:261-272 -- UNet2DConditionModel.forward, ControlNetModel.forward,
+ * AutoencoderKL.encode / .decode, CLIPTextModel(.WithProjection).forward.
+ *
+ * Mechanism: LAUNCH PROGRAMS.  The host walks a graph once, with the device buffers it will keep using (weights, static
+ * input / output / scratch tensors), between fie_program_begin and fie_program_end: every kernel launch the op entries below
+ * issue meanwhile is appended to the program (kernel, grid, block, LDS bytes, argument values) while still executing.
+ * fie_program_run re-issues the whole list on the ctx stream from C++: no host-side shape logic, no Python, asynchronous and
+ * hipGraph-capturable like any single op.  New inputs = new CONTENTS of the same input buffers.  The caller keeps every buffer
+ * the program references alive and destroys programs it created.
+ *   fie_graph_register binds a program to one of the names "unet_forward", "controlnet_forward", "vae_encode", "vae_decode",
+ *   "clip_text_forward"; the five named entries run the program bound to their name (FIE_EINVAL if none). */
+typedef struct fie_program fie_program;
+int fie_program_begin(fie_ctx* ctx, fie_program** out);
+int fie_program_end(fie_ctx* ctx);
+int fie_program_launches(const fie_program* p);             /* number of recorded launches (-1: NULL) */
+int fie_program_run(fie_ctx* ctx, const fie_program* p);
+int fie_program_destroy(fie_ctx* ctx, fie_program* p);      /* also drops its name bindings on ctx (ctx may be NULL) */
+int fie_graph_register(fie_ctx* ctx, const char* name, fie_program* p);
+int fie_unet_forward(fie_ctx* ctx);
+int fie_controlnet_forward(fie_ctx* ctx);
+int fie_vae_encode(fie_ctx* ctx);
+int fie_vae_decode(fie_ctx* ctx);
+int fie_clip_text_forward(fie_ctx* ctx);
+
 /* ---- K2 GEMM (Linear / 1x1 conv).  Replaces torch.nn.Linear / 1x1 Conv2d dispatched by upstream
  * diffusers models/attention.py, transformer_2d.py, resnet.py (conv_shortcut), controlnet.py (zero convs),
  * embeddings.py (TimestepEmbedding), transformers modeling_clip.py -- all reached from src/pipeline.py:261.
