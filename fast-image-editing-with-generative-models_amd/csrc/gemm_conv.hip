@@ -322,6 +322,7 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
 //   41 / 42 / 43   gemm3_kernel  128x128 / 128x64 / 64x64, 3 stages, 4 waves
 //   51             gemm3_kernel  128x128, 3 stages, 8 waves
 //   61 / 62        gemm3_kernel  256x256 x 2 stages / 256x128 x 3 stages, 8 waves
+//   + 1000 / + 2000  force the tile order (n-tiles / m-tiles fastest); plain codes estimate it
 //   81 / 82        gemm8_kernel  256x256 phased (82: second DMA piece of each phase inside the MFMA cluster, A/B: slower)
 struct TileDim { int code, bm, bn; };
 constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {41, 128, 128}, {42, 128, 64}, {43, 64, 64},
@@ -361,19 +362,32 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     } else {
         code = 43;
     }
-    int order = 0;                 // 0: n-tiles fastest (an XCD owns a range of activation rows), 1: m-tiles fastest
-    bool forced = false;
+    int order = -1;                // 0: n-tiles fastest (an XCD owns a range of activation rows), 1: m-tiles fastest; -1: estimate below
     for (int i = 0; i < ctx->n_overrides; ++i) {
         const fie_tile_override& o = ctx->overrides[i];
-        if (o.mode == (MODE == 1) && o.M == a.M && o.N == a.N && o.K == a.K) { code = o.code % 1000; order = o.code >= 2000; forced = true; }
+        if (o.mode == (MODE == 1) && o.M == a.M && o.N == a.N && o.K == a.K) { code = o.code % 1000; order = o.code >= 2000 ? 1 : o.code >= 1000 ? 0 : -1; }
     }
-    if (ctx->force_tile) { code = ctx->force_tile % 1000; order = ctx->force_tile >= 2000; forced = true; }
+    if (ctx->force_tile) { code = ctx->force_tile % 1000; order = ctx->force_tile >= 2000 ? 1 : ctx->force_tile >= 1000 ? 0 : -1; }
     const TileDim* t = nullptr;
     for (const TileDim& d : kTiles)
         if (d.code == code) t = &d;
     FIE_REQUIRE(t != nullptr, "unknown tile code %d", code);
     FIE_REQUIRE(code < 40 || dma_ok, "tile code %d: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)", code);
-    (void)forced;
+    if (order < 0) {
+        // Tile order = which operand an XCD re-streams past its 4 MiB L2.  Consecutive tile ids run on one XCD (xcd_remap), so an
+        // XCD owns T/8 consecutive tiles: with n fastest that is `dm` row blocks x up to all column tiles, with m fastest the
+        // transpose.  Fabric bytes per XCD ~ (row blocks touched) x (A bytes per row block) + (column tiles touched) x (W bytes per
+        // column tile); pick the smaller (FF1 at M 2048: 8 XCDs x all 26 MB of W with n fastest, 247 MB measured by PMC in round 1,
+        // against 8 x (3.3 MB of W + all 5.2 MB of A) with m fastest).  The 3x3 im2col view re-reads an input row block ~once.
+        const int64_t nbm = (a.M + t->bm - 1) / t->bm, nbn = (a.N + t->bn - 1) / t->bn;
+        const int64_t per_xcd = (nbm * nbn + 7) / 8;
+        const double a_tile = (double)t->bm * a.K * 2 * (MODE == 1 ? 1.0 / 9 : 1.0), w_tile = (double)t->bn * a.K * 2;
+        auto fabric = [&](int64_t fast, int64_t slow, double fast_tile, double slow_tile) {       // `fast` tiles per row of the id space
+            const int64_t rows = (per_xcd + fast - 1) / fast;                                       // slow-index values an XCD touches
+            return (double)(rows < slow ? rows : slow) * slow_tile + (double)(per_xcd < fast ? per_xcd : fast) * fast_tile;
+        };
+        order = fabric(nbm, nbn, a_tile, w_tile) < fabric(nbn, nbm, w_tile, a_tile) ? 1 : 0;
+    }
     if (a.w_scale) {                 // fp8 weights: the three W8 ring tiles (gemm_w8.hip)
         FIE_REQUIRE(dma_ok, "fp8 weights: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)");
         code = (code == 81 || code == 82 || code == 61 || code == 62) ? 62 : (code == 43 || code == 3) ? 43 : 42;

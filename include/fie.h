@@ -221,7 +221,7 @@ int fie_lcm_step_f32(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, floa
 /* ---- tuning / test hooks (not part of the drop-in surface).  Tile hooks are PER CTX: nothing process-global sits on the
  * launch path.  Tile codes: 1/2/3 register-staged 128x128 / 128x64 / 64x64 (any shape); 41/42/43 LDS-DMA ring 128x128 /
  * 128x64 / 64x64; 51 ring 128x128 x 8 waves; 61/62 ring 256x256 / 256x128 x 8 waves; 81 phased 256x256 (gemm8.hip).
- * + 2000: m-tiles fastest tile order.  A code the shape is not eligible for returns FIE_EINVAL from the op. */
+ * + 1000 / + 2000: force n-tiles / m-tiles fastest tile order (plain codes estimate the order that re-streams fewer bytes).  A code the shape is not eligible for returns FIE_EINVAL from the op. */
 int fie_debug_force_tile(fie_ctx* ctx, int tile);                  /* 0 = heuristic */
 int fie_debug_tile_override(fie_ctx* ctx, const char* spec);       /* "mode,M,N,K=code;..." (mode 0 GEMM, 1 conv); NULL clears; returns the count */
 int fie_debug_gemm_probe(fie_ctx* ctx, int mode);                  /* TIMING-ONLY probes of the LDS-DMA kernels (outputs are wrong): 0 off, 1 = DMA loads dropped, 2 = every tile loads tile (0,0) */
