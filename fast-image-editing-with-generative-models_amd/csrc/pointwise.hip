@@ -26,18 +26,23 @@ __global__ void sinusoid_kernel(const float* vals, int B, int nvals, int dim, T*
 //     out[b, :] = SiLU( W2 SiLU(W1 sinus(t_b) + b1) + b2 + add[b, :] )
 // = Timesteps(C0, flip_sin_to_cos, shift 0) -> TimestepEmbedding (Linear, SiLU, Linear) -> + text-time embedding -> the SiLU every
 // resnet applies in front of its time projection (upstream embeddings.py, resnet.py) -- ONE launch instead of sinusoid + two GEMM
-// launches whose M is the batch (2 rows).  One wave per output neuron: lanes stride the K dimension in 16-byte vectors, fp32
-// accumulation, wave reduction by shuffles.  Every block evaluates layer 1 completely (E x C0 MACs per row; W1's 0.8 MB stay in L2)
-// and 64 neurons of layer 2; the intermediate vectors are rounded to the storage type exactly where the unfused path stores them.
-constexpr int kTeMaxB = 16;
+// launches whose M is the batch (2 rows).  E / 64 workgroups; workgroup i owns neurons [64 i, 64 i + 64) of BOTH layers, a thread
+// owns a quarter of one neuron's K range (all its 16-byte weight loads are independent and in flight together; the four quarters
+// meet by two shuffles).  Between the layers the workgroups exchange the hidden vector through `ws` behind a counter barrier
+// (cdna_hip_programming.md Guideline 16: every storing wave drains, one agent-scope release + relaxed arrive per workgroup, relaxed
+// poll + ONE agent-scope acquire; E / 64 <= 256 workgroups are co-resident by grid size; the spin is bounded).  The last workgroup
+// to leave resets the two counters, so the zero-initialised workspace is clean for the next launch on the same stream.
+constexpr int kTeMaxB = 4;
 
 __global__ __launch_bounds__(256) void time_embed_kernel(const float* t, int B, int C0, int E, const half_t* W1, const half_t* b1,
                                                          const half_t* W2, const half_t* b2, const half_t* add, int64_t ld_add,
-                                                         half_t* out, int64_t ld_out) {
+                                                         half_t* out, int64_t ld_out, half_t* hbuf, unsigned* sync) {
     extern __shared__ __attribute__((aligned(16))) half_t te_smem[];
-    half_t* x = te_smem;                       // [B][C0]
-    half_t* h = te_smem + B * C0;              // [B][E]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    half_t* x = te_smem;                       // [B][C0]   sinusoid, storage type (as the unfused path stores it)
+    half_t* h = te_smem + kTeMaxB * 512;       // [B][E]    hidden vector after the barrier
+    const int tid = threadIdx.x;
+    const int nl = tid >> 2, kq = tid & 3;     // neuron inside the workgroup, K quarter
+    const int n = blockIdx.x * 64 + nl;
     const int half_c = C0 / 2;
     for (int i = tid; i < B * half_c; i += 256) {
         const int b = i / half_c, f = i - b * half_c;
@@ -46,50 +51,75 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* t, int B, 
         x[b * C0 + half_c + f] = (half_t)sinf(arg);
     }
     __syncthreads();
-    auto dot_rows = [&](const half_t* wrow, const half_t* vec, int K, float (&acc)[kTeMaxB]) {
+    auto quarter_dot = [&](const half_t* wrow, const half_t* vec, int K, float (&acc)[kTeMaxB]) {
+        const int k0 = kq * (K / 4), k1 = k0 + K / 4;                  // K % 32 == 0: whole 16-byte vectors per quarter
 #pragma unroll
         for (int b = 0; b < kTeMaxB; ++b) acc[b] = 0.f;
-        for (int k = lane * 8; k < K; k += 512) {
+#pragma unroll 8
+        for (int k = k0; k < k1; k += 8) {
             float w[8];
             fie_load8(wrow + k, w);
 #pragma unroll
-            for (int b = 0; b < kTeMaxB; ++b) {
+            for (int b = 0; b < kTeMaxB; ++b)
                 if (b < B) {
                     float v[8];
                     fie_load8(vec + b * K + k, v);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[b] += w[j] * v[j];
                 }
-            }
         }
 #pragma unroll
-        for (int b = 0; b < kTeMaxB; ++b)
-            if (b < B) {
-#pragma unroll
-                for (int o = 32; o; o >>= 1) acc[b] += __shfl_xor(acc[b], o);
-            }
+        for (int b = 0; b < kTeMaxB; ++b) {
+            acc[b] += __shfl_xor(acc[b], 1);
+            acc[b] += __shfl_xor(acc[b], 2);
+        }
     };
     float acc[kTeMaxB];
-    for (int n = wave; n < E; n += 4) {                                  // layer 1, all of it
-        dot_rows(W1 + (int64_t)n * C0, x, C0, acc);
-        if (lane < B) {
-            float v = 0.f;
+    // ---- layer 1: this workgroup's 64 neurons -> hbuf
+    if (n < E) {
+        quarter_dot(W1 + (int64_t)n * C0, x, C0, acc);
+        if (kq == 0) {
+            const float bias = (float)b1[n];
 #pragma unroll
-            for (int b = 0; b < kTeMaxB; ++b) v = lane == b ? acc[b] : v;
-            h[lane * E + n] = (half_t)fie_silu(v + (float)b1[n]);
+            for (int b = 0; b < kTeMaxB; ++b)
+                if (b < B) hbuf[b * E + n] = (half_t)fie_silu(acc[b] + bias);
         }
     }
+    // ---- barrier across the E / 64 workgroups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // every storing wave drains its stores
     __syncthreads();
-    for (int q = wave; q < 64; q += 4) {                                 // layer 2, this block's 64 neurons
-        const int n = blockIdx.x * 64 + q;
-        if (n >= E) break;
-        dot_rows(W2 + (int64_t)n * E, h, E, acc);
-        if (lane < B) {
-            float v = 0.f;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (int i = tid * 8; i < B * E; i += 256 * 8) {                    // hidden vector -> LDS (plain loads behind the acquire)
+        float v[8];
+        fie_load8(hbuf + i, v);
+        fie_store8(h + i, v);
+    }
+    __syncthreads();
+    // ---- layer 2: the same 64 neuron indices of the output
+    if (n < E) {
+        quarter_dot(W2 + (int64_t)n * E, h, E, acc);
+        if (kq == 0) {
+            const float bias = (float)b2[n];
 #pragma unroll
-            for (int b = 0; b < kTeMaxB; ++b) v = lane == b ? acc[b] : v;
-            v += (float)b2[n] + (add ? (float)add[(int64_t)lane * ld_add + n] : 0.f);
-            out[(int64_t)lane * ld_out + n] = (half_t)fie_silu(v);
+            for (int b = 0; b < kTeMaxB; ++b)
+                if (b < B) out[(int64_t)b * ld_out + n] = (half_t)fie_silu(acc[b] + bias + (add ? (float)add[(int64_t)b * ld_add + n] : 0.f));
+        }
+    }
+    // ---- leave: the last workgroup out resets the counters (all have passed the poll by then: each left only after seeing the full count)
+    if (tid == 0) {
+        const unsigned left = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == gridDim.x - 1) {
+            __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -272,14 +302,20 @@ int fie_sinusoid_f16(fie_ctx* ctx, const float* vals, int B, int nvals, int dim,
 int fie_sinusoid_f32(fie_ctx* ctx, const float* vals, int B, int nvals, int dim, void* out, int64_t ld_out, int col0) {
     return sinusoid_t<float>(ctx, vals, B, nvals, dim, out, ld_out, col0);
 }
+int64_t fie_time_embed_workspace_bytes(int E) { return (int64_t)kTeMaxB * E * (int64_t)sizeof(half_t) + 16; }
+
 int fie_time_embed_f16(fie_ctx* ctx, const float* t, int B, int C0, int E, const void* W1, const void* b1, const void* W2, const void* b2,
-                       const void* add, int64_t ld_add, void* out, int64_t ld_out) {
-    FIE_REQUIRE(ctx && t && W1 && b1 && W2 && b2 && out, "fie_time_embed_f16: NULL argument");
-    FIE_REQUIRE(B > 0 && B <= kTeMaxB && C0 > 0 && C0 % 16 == 0 && E > 0 && E % 8 == 0 && ld_out >= E && (!add || ld_add >= E),
-                "fie_time_embed_f16: bad shape (B <= %d, C0 %% 16 == 0, E %% 8 == 0)", kTeMaxB);
-    const int lds = B * (C0 + E) * (int)sizeof(half_t);
-    FIE_REQUIRE(lds <= 64 * 1024, "fie_time_embed_f16: B * (C0 + E) too large");
-    fie_launch(ctx, time_embed_kernel, dim3((E + 63) / 64), dim3(256), lds, t, B, C0, E, (const half_t*)W1, (const half_t*)b1, (const half_t*)W2, (const half_t*)b2, (const half_t*)add, ld_add, (half_t*)out, ld_out);
+                       const void* add, int64_t ld_add, void* out, int64_t ld_out, void* workspace) {
+    FIE_REQUIRE(ctx && t && W1 && b1 && W2 && b2 && out && workspace, "fie_time_embed_f16: NULL argument");
+    FIE_REQUIRE(B > 0 && B <= kTeMaxB && C0 > 0 && C0 % 32 == 0 && C0 <= 512 && E > 0 && E % 64 == 0 && E <= 256 * 64 && ld_out >= E &&
+                    (!add || ld_add >= E),
+                "fie_time_embed_f16: bad shape (B <= %d, C0 %% 32 == 0 and <= 512, E %% 64 == 0)", kTeMaxB);
+    const int lds = kTeMaxB * (512 + E) * (int)sizeof(half_t);
+    FIE_REQUIRE(lds <= 64 * 1024, "fie_time_embed_f16: E too large");
+    half_t* hbuf = (half_t*)workspace;
+    unsigned* sync = (unsigned*)((char*)workspace + (int64_t)kTeMaxB * E * sizeof(half_t));      // must be ZERO before the first launch
+    fie_launch(ctx, time_embed_kernel, dim3(E / 64), dim3(256), (unsigned)lds, t, B, C0, E, (const half_t*)W1, (const half_t*)b1,
+               (const half_t*)W2, (const half_t*)b2, (const half_t*)add, ld_add, (half_t*)out, ld_out, hbuf, sync);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

@@ -46,7 +46,8 @@ SIGNATURES = {
     "fie_groupnorm_nhwc_f16": [_P, _P, _I, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P],
     "fie_layernorm_f16": [_P, _P, _L, _P, _L, _L, _I, _P, _P, _F],
     "fie_sinusoid_f16": [_P, _P, _I, _I, _I, _P, _L, _I],
-    "fie_time_embed_f16": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P, _L],
+    "fie_time_embed_workspace_bytes": [_I],
+    "fie_time_embed_f16": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P, _L, _P],
     "fie_clip_embed_f16": [_P, _P, _I, _I, _I, _P, _P, _P],
     "fie_pixels_in_u8_f16": [_P, _P, _I, _I, _I, _P, _I],
     "fie_pixels_out_f16_u8": [_P, _P, _L, _I, _I, _P],
@@ -100,7 +101,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.argtypes = args
-            fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes") else _I
+            fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes", "fie_time_embed_workspace_bytes") else _I
         _lib.fie_last_error.restype = ctypes.c_char_p
         _lib.fie_last_error.argtypes = []
         _lib.fie_debug_last_gemm_kernel.restype = ctypes.c_char_p
@@ -403,13 +404,17 @@ class Context:
         _chk((lib().fie_sinusoid_f32 if self.f32 else lib().fie_sinusoid_f16)(self.h, _p(vals), b, nv, dim, _p(out), out.stride(0), col0))
         return out
 
-    def time_embed(self, t, w1, b1, w2, b2, add=None):
-        """K7 fused: silu(W2 silu(W1 sinusoid(t) + b1) + b2 + add) for the B rows of one step; w1 [E, C0], w2 [E, E] plain f16."""
+    def time_embed_workspace(self, e):
+        """Zero-filled workspace of the fused timestep-embedding kernel (one per model: launches on one stream reuse it)."""
+        return torch.zeros(lib().fie_time_embed_workspace_bytes(e), device=self.device, dtype=torch.uint8)
+
+    def time_embed(self, t, w1, b1, w2, b2, ws, add=None):
+        """K7 fused: silu(W2 silu(W1 sinusoid(t) + b1) + b2 + add) for the B <= 4 rows of one step; w1 [E, C0], w2 [E, E] plain f16."""
         self.sync_stream()
         b, (e, c0) = t.numel(), w1.shape
         out = self._alloc((b, e), torch.float16)
         _chk(lib().fie_time_embed_f16(self.h, _p(t), b, c0, e, _p(w1), _p(b1), _p(w2), _p(b2), _p(add),
-                                      add.stride(0) if add is not None else 0, _p(out), out.stride(0)))
+                                      add.stride(0) if add is not None else 0, _p(out), out.stride(0), _p(ws)))
         return out
 
     def clip_embed(self, ids, tok, pos):

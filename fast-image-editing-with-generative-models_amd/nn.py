@@ -155,8 +155,12 @@ class _CondNet:
         self.t1, self.t2 = Linear(ctx, sd, "time_embedding.linear_1", quant=False), Linear(ctx, sd, "time_embedding.linear_2", quant=False)
         self.a1, self.a2 = Linear(ctx, sd, "add_embedding.linear_1", quant=False), Linear(ctx, sd, "add_embedding.linear_2", quant=False)
         # fp16 path: the per-step timestep embedding runs in ONE fused kernel (fie_time_embed_f16) on the plain weights
-        self.te = None if ctx.f32 else tuple(_dev(ctx, sd[k]) for k in ("time_embedding.linear_1.weight", "time_embedding.linear_1.bias",
-                                                                         "time_embedding.linear_2.weight", "time_embedding.linear_2.bias"))
+        te_dim, ch0 = time_embed_dim(cfg), chans[0]
+        self.te = None
+        if not ctx.f32 and te_dim % 64 == 0 and ch0 % 32 == 0 and ch0 <= 512:
+            self.te = tuple(_dev(ctx, sd[k]) for k in ("time_embedding.linear_1.weight", "time_embedding.linear_1.bias",
+                                                       "time_embedding.linear_2.weight", "time_embedding.linear_2.bias"))
+            self.te_ws = {}                       # per graph slot (ctx.ws_tag): edits in flight must not share the barrier counters
         self.down = []
         for i in range(len(chans)):
             layers = []
@@ -216,8 +220,11 @@ class _CondNet:
         """silu(time_emb + add_emb) -> all resnets' time projections in one GEMM.  t_dev: f32 [B, 1] on device."""
         ctx = self.ctx
         ch0 = self.cfg["block_out_channels"][0]
-        if self.te is not None and t_dev.shape[0] <= 16:
-            return self.temb_proj(ctx, ctx.time_embed(t_dev, *self.te, add=self.add_emb))
+        if self.te is not None and t_dev.shape[0] <= 4:
+            ws = self.te_ws.get(ctx.ws_tag)
+            if ws is None:
+                ws = self.te_ws[ctx.ws_tag] = ctx.time_embed_workspace(self.te[0].shape[0])
+            return self.temb_proj(ctx, ctx.time_embed(t_dev, *self.te, ws, add=self.add_emb))
         s = torch.empty((t_dev.shape[0], ch0), device=ctx.device, dtype=ctx.dtype)
         ctx.sinusoid(t_dev, ch0, s)
         # emb = time_emb + add_emb; resnets consume Linear(SiLU(emb)): add_emb rides in as a per-row bias so the

@@ -127,9 +127,12 @@ int fie_sinusoid_f16(fie_ctx* ctx, const float* vals, int B, int nvals, int dim,
  * the SiLU in front of every resnet's time projection).  Replaces Timesteps + TimestepEmbedding of embeddings.py and the
  * `emb = emb + aug_emb` / `nonlinearity(temb)` steps of unet_2d_condition.py / resnet.py for the M = batch rows of one step.
  *   t: f32 [B] on the device; W1 [E][C0], W2 [E][E] plain row-major f16 (NOT packed), b1, b2 [E]; add: [B][ld_add] f16 or NULL;
- *   out[b, n] = silu(W2 silu(W1 [cos(t f) | sin(t f)] + b1) + b2 + add[b, n]).  B <= 16, C0 % 16 == 0, E % 8 == 0. */
+ *   out[b, n] = silu(W2 silu(W1 [cos(t f) | sin(t f)] + b1) + b2 + add[b, n]).  B <= 4, C0 % 32 == 0, E % 64 == 0.
+ *   workspace: fie_time_embed_workspace_bytes(E) bytes, ZERO-filled once by the caller (hidden vector + the two counters of the
+ *   in-launch barrier between the layers; the kernel leaves the counters at zero).  One workspace per stream / model. */
+int64_t fie_time_embed_workspace_bytes(int E);
 int fie_time_embed_f16(fie_ctx* ctx, const float* t, int B, int C0, int E, const void* W1, const void* b1, const void* W2,
-                       const void* b2, const void* add, int64_t ld_add, void* out, int64_t ld_out);
+                       const void* b2, const void* add, int64_t ld_add, void* out, int64_t ld_out, void* workspace);
 
 /* ---- K12 token + position embedding gather (CLIPTextEmbeddings). ids: int32 [B*T] on device. */
 int fie_clip_embed_f16(fie_ctx* ctx, const int32_t* ids, int B, int T, int C, const void* tok_table,

@@ -421,21 +421,28 @@ def test_tile_override_steers_one_shape(fie):
 
 
 def test_time_embed_fused(fie):
-    """K7 fused kernel against the unfused route it replaces semantically (embeddings.py): sinusoid -> Linear -> SiLU -> Linear,
-    + the text-time embedding, SiLU; SDXL dims (320 -> 1280 -> 1280), batch 2 and 16, t = 499 KAT of SURVEY A.1 on the way."""
+    """K7 fused kernel against the unfused route it replaces (embeddings.py): sinusoid -> Linear -> SiLU -> Linear, + the
+    text-time embedding, SiLU; SDXL dims (320 -> 1280 -> 1280) and the tiny stack's (64 -> 256), batch 1 / 2 / 4, t = 499 KAT
+    of SURVEY A.1 on the way; 50 back-to-back launches on one workspace are bit-identical (the in-launch barrier between the
+    layers resets its counters; a stale hidden vector would show)."""
     import math
-    for b in (1, 2, 16):
-        g = torch.Generator().manual_seed(b)
-        t = torch.tensor([499.0, 259.0, 999.0, 0.0] * 4)[:b]
-        w1, b1 = rnd(1280, 320, seed=1, scale=320 ** -0.5), rnd(1280, seed=2, scale=0.1)
-        w2, b2 = rnd(1280, 1280, seed=3, scale=1280 ** -0.5), rnd(1280, seed=4, scale=0.1)
-        add = rnd(b, 1280, seed=5)
-        out = fie.time_embed(t.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), add=add.to(DEV))
-        f = torch.exp(-math.log(10000.0) * torch.arange(160, dtype=torch.float32) / 160)
-        x = torch.cat([torch.cos(t[:, None] * f), torch.sin(t[:, None] * f)], 1)
-        if b >= 1:
-            assert torch.allclose(x[0, :3], torch.tensor([-0.87116218, 0.98838931, 0.19755381]), atol=1e-5)
-        h = F.silu(x.half().float() @ w1.float().T + b1.float()).half().float()
-        ref = F.silu(h @ w2.float().T + b2.float() + add.float())
-        assert rel_err(out, ref) < 3e-3
-        assert rel_err(fie.time_embed(t.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV)), F.silu(h @ w2.float().T + b2.float())) < 3e-3
+    for c0, e in ((320, 1280), (64, 256)):
+        ws = fie.time_embed_workspace(e)
+        for b in (1, 2, 4):
+            t = torch.tensor([499.0, 259.0, 999.0, 0.0])[:b]
+            w1, b1 = rnd(e, c0, seed=1, scale=c0 ** -0.5), rnd(e, seed=2, scale=0.1)
+            w2, b2 = rnd(e, e, seed=3, scale=e ** -0.5), rnd(e, seed=4, scale=0.1)
+            add = rnd(b, e, seed=5)
+            dev = [v.to(DEV) for v in (t, w1, b1, w2, b2)]
+            out = fie.time_embed(*dev, ws, add=add.to(DEV))
+            f = torch.exp(-math.log(10000.0) * torch.arange(c0 // 2, dtype=torch.float32) / (c0 // 2))
+            x = torch.cat([torch.cos(t[:, None] * f), torch.sin(t[:, None] * f)], 1)
+            if c0 == 320:
+                assert torch.allclose(x[0, :3], torch.tensor([-0.87116218, 0.98838931, 0.19755381]), atol=1e-5)
+            h = F.silu(x.half().float() @ w1.float().T + b1.float()).half().float()
+            assert rel_err(out, F.silu(h @ w2.float().T + b2.float() + add.float())) < 3e-3
+            assert rel_err(fie.time_embed(*dev, ws), F.silu(h @ w2.float().T + b2.float())) < 3e-3
+            first = fie.time_embed(*dev, ws, add=add.to(DEV)).clone()
+            for _ in range(50):
+                assert torch.equal(fie.time_embed(*dev, ws, add=add.to(DEV)), first)
+        assert int(ws[-16:-8].view(torch.int32).abs().sum()) == 0          # both barrier counters back at zero
