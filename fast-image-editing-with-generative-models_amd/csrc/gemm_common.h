@@ -30,7 +30,7 @@ struct GemmArgs {
     int nbm, nbn;
     int64_t a1_bytes, a2_bytes, w_bytes;   // operand extents for the v3 buffer descriptors
     const float* w_scale;                   // fp8 weights (gemm_w8.hip): per-output-channel dequantisation scale [N], applied to the accumulator first; Wt then points at e4m3 bytes and ldw counts bytes
-    int probe;                              // timing-only probes (fie_debug_gemm_probe; outputs are wrong): 1 = every DMA load dropped (zero-record descriptors), 2 = every tile fetches tile (0,0)'s operands (all L2 hits)
+    int probe;                              // timing-only probes (fie_debug_gemm_probe; outputs are wrong): 1 = every DMA load dropped (zero-record descriptors), 2 = every tile fetches tile (0,0)'s operands (all L2 hits), 3 = ring kernels issue no DMA inside the K loop (MFMA + ds_read + barrier floor)
     int order;                              // 0: n-tiles fastest (an XCD owns a range of rows), 1: m-tiles fastest (an XCD owns a range of columns)
 };
 

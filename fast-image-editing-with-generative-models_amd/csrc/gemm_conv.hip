@@ -277,7 +277,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             // the refill of the freed stage is issued in two halves, one in front of each MFMA group, so that no wave
             // spends a whole K-step's worth of LDS-DMA issue slots before its first MFMA
             // (measured: pays for the 8-wave blocks, costs 10 % on the 4-wave ones, which keep one burst per K-step)
-            if (more) {
+            if (more && p.probe != 3) {                // probe 3: no DMA issued inside the K loop at all (stale LDS data)
                 if (kk == 0) { issue(kt + ST - 1, fill); if (NW != 8) issue_w(kt + ST - 1, fill); }
                 else if (NW == 8) issue_w(kt + ST - 1, fill);
             }
@@ -506,7 +506,7 @@ int fie_debug_tile_override(fie_ctx* ctx, const char* spec) {
 }
 
 int fie_debug_gemm_probe(fie_ctx* ctx, int mode) {
-    FIE_REQUIRE(ctx != nullptr && mode >= 0 && mode <= 2, "fie_debug_gemm_probe: bad argument");
+    FIE_REQUIRE(ctx != nullptr && mode >= 0 && mode <= 3, "fie_debug_gemm_probe: bad argument");
     ctx->gemm_probe = mode;
     return FIE_OK;
 }

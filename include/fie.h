@@ -227,7 +227,7 @@ int fie_lcm_step_f32(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, floa
  * + 1000 / + 2000: force n-tiles / m-tiles fastest tile order (plain codes estimate the order that re-streams fewer bytes).  A code the shape is not eligible for returns FIE_EINVAL from the op. */
 int fie_debug_force_tile(fie_ctx* ctx, int tile);                  /* 0 = heuristic */
 int fie_debug_tile_override(fie_ctx* ctx, const char* spec);       /* "mode,M,N,K=code;..." (mode 0 GEMM, 1 conv); NULL clears; returns the count */
-int fie_debug_gemm_probe(fie_ctx* ctx, int mode);                  /* TIMING-ONLY probes of the LDS-DMA kernels (outputs are wrong): 0 off, 1 = DMA loads dropped, 2 = every tile loads tile (0,0) */
+int fie_debug_gemm_probe(fie_ctx* ctx, int mode);                  /* TIMING-ONLY probes of the LDS-DMA kernels (outputs are wrong): 0 off, 1 = DMA loads dropped by the descriptor, 2 = every tile loads tile (0,0), 3 = ring kernels: no DMA issued in the K loop */
 const char* fie_debug_last_gemm_kernel(fie_ctx* ctx);              /* kernel / tile of the last fie_gemm_f16 / fie_conv3x3_nhwc_f16 launch */
 int fie_debug_attn_variant(int variant);   /* 0 = default kernel, 1 = first-generation kernel (A/B benchmarking) */
 int fie_debug_gn_onepass(int enable);      /* 1 = default (single-pass GroupNorm on small maps), 0 = always partial/finalize/apply */
