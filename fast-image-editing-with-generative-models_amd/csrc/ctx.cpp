@@ -129,6 +129,8 @@ int fie_ctx_set_stream(fie_ctx* ctx, void* stream) {
 }
 
 int fie_ctx_destroy(fie_ctx* ctx) {
+    if (ctx && ctx->tune_buf) (void)hipFree(ctx->tune_buf);
+    if (ctx && ctx->tune_flush) (void)hipFree(ctx->tune_flush);
     delete ctx;                       // registered programs are owned by the caller (fie_program_destroy)
     return FIE_OK;
 }

@@ -36,6 +36,13 @@ struct fie_program {
 
 struct fie_tile_override { int mode, M, N, K, code; };   // tuning hook: per-shape GEMM / conv tile code (mode 0 GEMM, 1 conv)
 
+struct fie_tune_key {      // one GEMM / conv problem as the autotuner sees it
+    int mode, M, N, K, K1, geom, w8;
+    bool operator<(const fie_tune_key& o) const {
+        return std::tie(mode, M, N, K, K1, geom, w8) < std::tie(o.mode, o.M, o.N, o.K, o.K1, o.geom, o.w8);
+    }
+};
+
 struct fie_ctx {
     int device;
     hipStream_t stream;
@@ -43,6 +50,12 @@ struct fie_ctx {
     // tuning / test hooks of the GEMM launch table (fie_debug_*): per ctx, never process-global
     int force_tile = 0;
     int gemm_probe = 0;
+    unsigned* gemm_stamps = nullptr;
+    int autotune = 0;                        // fie_gemm_autotune: time the eligible tiles at a shape's first eager launch
+    std::map<fie_tune_key, int> tuned;
+    void* tune_buf = nullptr;                // scratch output of the timing launches
+    void* tune_flush = nullptr;              // 384 MB written between timed launches: cold weights, as inside the network
+    size_t tune_bytes = 0;
     int n_overrides = 0;
     fie_tile_override overrides[32];
     char last_kernel[96] = "";

@@ -30,7 +30,8 @@ struct GemmArgs {
     int nbm, nbn;
     int64_t a1_bytes, a2_bytes, w_bytes;   // operand extents for the v3 buffer descriptors
     const float* w_scale;                   // fp8 weights (gemm_w8.hip): per-output-channel dequantisation scale [N], applied to the accumulator first; Wt then points at e4m3 bytes and ldw counts bytes
-    int probe;                              // timing-only probes (fie_debug_gemm_probe; outputs are wrong): 1 = every DMA load dropped (zero-record descriptors), 2 = every tile fetches tile (0,0)'s operands (all L2 hits), 3 = ring kernels issue no DMA inside the K loop (MFMA + ds_read + barrier floor)
+    unsigned* stamps;                       // tile codes 97 / 98: [tile][wave][8] cycle sums of the K-loop segments (fie_debug_gemm_stamps), else NULL
+    int probe;                              // timing-only probes (fie_debug_gemm_probe; outputs are wrong): 1 = every DMA load dropped (zero-record descriptors), 2 = every tile fetches tile (0,0)'s operands (all L2 hits), 3 = ring kernels issue no DMA inside the K loop (MFMA + ds_read + barrier floor), 4 = no epilogue (nothing stored)
     int order;                              // 0: n-tiles fastest (an XCD owns a range of rows), 1: m-tiles fastest (an XCD owns a range of columns)
 };
 
@@ -39,6 +40,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + (
 template <int FM, int FN, int WM, int WN>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
+    if (p.probe == 4 && p.M > 0) return;                    // timing probe: no epilogue at all (p.M > 0 keeps the accumulators live)
     // ---- epilogue: lane holds C[m = .. + fr][n = .. + fq*4 + (0..3)]
 #pragma unroll
     for (int j = 0; j < FM; ++j) {

@@ -13,9 +13,12 @@
 //
 // Unselected experiments of round 1 (zero-page global_load_lds ring, ping-pong, four-phase, producer waves, halo-reuse conv,
 // 160-wide tiles, column split) are archived, unbuilt, in tools/experiments/gemm_variants_r01.hip.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
+
 #include "gemm_common.h"
 
 using namespace fie_gemm;
@@ -152,7 +155,19 @@ __device__ __forceinline__ void wait_stage(int later) {
     else wait_vm_barrier<0>();
 }
 
-template <int BM, int BN, int ST, int MODE, int NW>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0
+// LDS fragment reads as asm: asynchronous, valid after an explicit lgkmcnt wait (prefetching ring kernels only)
+template <int OFF>
+__device__ __forceinline__ f16x8 lds_read16_async(unsigned addr) {
+    f16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N, int... I>
+__device__ __forceinline__ void read_frags(f16x8 (&f)[N], unsigned addr, std::integer_sequence<int, I...>) {
+    ((f[I] = lds_read16_async<I * 16 * BK * 2>(addr)), ...);
+}
+
+template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0
 __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     constexpr int WGN = NW / 2;
     constexpr int WM = BM / 2, WN = BN / WGN;
@@ -266,12 +281,87 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
 
     const int fr = lane & 15, fq = lane >> 4;
     int stage = 0, fill = ST - 1;
+    auto frags = [&](f16x8* fw, f16x8* fa, const half_t* sa, int kk) {
+        const half_t* sw = sa + BM * BK;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) fw[i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * WN + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + j * 16 + fr, kk * 4 + fq));
+    };
+    auto mfmas = [&](const f16x8* fw, const f16x8* fa) {
+        if (NW == 8) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        if (NW == 8) __builtin_amdgcn_s_setprio(0);
+    };
+    // STAMP instances (tile codes 97 / 98, fie_debug_gemm_stamps): per-wave cycle sums of the K-loop segments, s_memtime deltas
+    unsigned seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;      // [7] prologue, [8] epilogue, [9] / [10] entry / exit time
+    auto stamp = [&](int i) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+            seg[i] += t - tprev;
+            tprev = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (STAMP) tprev = seg[9] = (unsigned)__builtin_amdgcn_s_memtime();
+    if constexpr (PF) {
+        // Fragment reads run one half K-step ahead of the MFMAs that use them: the block's waves leave each barrier together, so
+        // without this every wave reads LDS at the same time (matrix cores idle) and then all issue MFMAs (LDS idle).
+        // The reads are inline asm with explicit counted waits: the compiler's own wait insertion falls back to lgkmcnt(0) in
+        // this loop (scalar loads pending at loop entry share the counter), which serialises exactly what this path overlaps.
+        static_assert(FM + FN <= 15, "lgkmcnt is a 4-bit counter");
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) half_t*)smem;
+        unsigned a_rd[2], w_rd[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            a_rd[kk] = lds0 + 2u * (unsigned)lds_off(wm * WM + fr, kk * 4 + fq);
+            w_rd[kk] = lds0 + 2u * (unsigned)(BM * BK + lds_off(wn * WN + fr, kk * 4 + fq));
+        }
+        f16x8 fw0[FN], fa0[FM], fw1[FN], fa1[FM];
+        auto reads = [&](f16x8 (&fw)[FN], f16x8 (&fa)[FM], int st, int kk) {
+            const unsigned so = (unsigned)st * (STAGE * 2);
+            read_frags(fw, w_rd[kk] + so, std::make_integer_sequence<int, FN>{});
+            read_frags(fa, a_rd[kk] + so, std::make_integer_sequence<int, FM>{});
+        };
+        auto landed = [&](f16x8 (&fw)[FN], f16x8 (&fa)[FM]) {     // MFMAs on these fragments stay behind the wait in front
+#pragma unroll
+            for (int i = 0; i < FN; ++i) asm volatile("" : "+v"(fw[i]));
+#pragma unroll
+            for (int j = 0; j < FM; ++j) asm volatile("" : "+v"(fa[j]));
+        };
+        wait_stage<NP, ST>(min(ST - 2, nk - 1));
+        reads(fw0, fa0, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            stamp(kt == 0 ? 7 : 0);                        // whole K-steps only: a stamp drains lgkmcnt
+            const bool more = kt + ST - 1 < nk && p.probe != 3;
+            if (more) { issue(kt + ST - 1, fill); if (NW != 8) issue_w(kt + ST - 1, fill); }
+            reads(fw1, fa1, stage, 1);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
+            landed(fw0, fa0);
+            mfmas(fw0, fa0);
+            if (more && NW == 8) issue_w(kt + ST - 1, fill);
+            stage = stage + 1 == ST ? 0 : stage + 1;
+            fill = fill + 1 == ST ? 0 : fill + 1;
+            // every read of the stage consumed in this K-step has returned before any wave may refill it (next iteration)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            landed(fw1, fa1);
+            if (kt + 1 < nk) {
+                wait_stage<NP, ST>(min(kt + ST - 1, nk - 1) - (kt + 1));
+                reads(fw0, fa0, stage, 0);
+            }
+            mfmas(fw1, fa1);
+        }
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const int later = min(kt + ST - 2, nk - 1) - kt;
         wait_stage<NP, ST>(later);
+        stamp(kt == 0 ? 7 : 0);                            // 0: MFMA drain + barrier wait
         const bool more = kt + ST - 1 < nk;
         const half_t* sa = smem + stage * STAGE;
-        const half_t* sw = sa + BM * BK;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // the refill of the freed stage is issued in two halves, one in front of each MFMA group, so that no wave
@@ -281,40 +371,43 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
                 if (kk == 0) { issue(kt + ST - 1, fill); if (NW != 8) issue_w(kt + ST - 1, fill); }
                 else if (NW == 8) issue_w(kt + ST - 1, fill);
             }
+            stamp(1 + 3 * kk);                             // 1 / 4: DMA issue
             f16x8 fw[FN], fa[FM];
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-                fw[i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * WN + i * 16 + fr, kk * 4 + fq));
-#pragma unroll
-            for (int j = 0; j < FM; ++j)
-                fa[j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + j * 16 + fr, kk * 4 + fq));
-            if (NW == 8) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-            if (NW == 8) __builtin_amdgcn_s_setprio(0);
+            frags(fw, fa, sa, kk);
+            if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp(2 + 3 * kk);                             // 2 / 5: fragment reads issued and landed
+            mfmas(fw, fa);
+            stamp(3 + 3 * kk);                             // 3 / 6: 16 MFMAs issued
         }
         stage = stage + 1 == ST ? 0 : stage + 1;
         fill = fill + 1 == ST ? 0 : fill + 1;
     }
+    stamp(11);                                             // last MFMA group issued
     epilogue<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's stores have left the wave
+        stamp(8);
+        seg[10] = tprev;
+        if (p.stamps && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) p.stamps[((size_t)bid * NW + wave) * 12 + i] = seg[i];
+        }
+    }
 }
 
 template <int BM, int BN, int ST, int NW>
 constexpr int ring_lds() { return ST * (BM + BN) * BK * (int)sizeof(half_t); }
 
-template <int BM, int BN, int ST, int MODE, int NW>
+template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false>
 hipError_t ring_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds<BM, BN, ST, NW>());
 }
 
-template <int BM, int BN, int ST, int MODE, int NW>
+template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false>
 void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
     constexpr int lds = ring_lds<BM, BN, ST, NW>();
-    fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW>), grid, dim3(NW * 64), lds, a);
+    fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP>), grid, dim3(NW * 64), lds, a);
 }
 
 // ---- tile codes (also the values fie_debug_force_tile / fie_debug_tile_override take)
@@ -323,18 +416,20 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
 //   51             gemm3_kernel  128x128, 3 stages, 8 waves
 //   61 / 62        gemm3_kernel  256x256 x 2 stages / 256x128 x 3 stages, 8 waves
 //   + 1000 / + 2000  force the tile order (n-tiles / m-tiles fastest); plain codes estimate it
+//   91 / 92 / 93 / 95 / 96   gemm3_kernel 41 / 42 / 43 / 51 / 62 with fragment reads one half K-step ahead of the MFMAs
+//   97 / 98 / 94   62 / 96 / 42 with in-kernel cycle stamps (fie_debug_gemm_stamps; slower, for tools/kstep_stamps.py only)
 //   81 / 82        gemm8_kernel  256x256 phased (82: second DMA piece of each phase inside the MFMA cluster, A/B: slower)
 struct TileDim { int code, bm, bn; };
 constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {41, 128, 128}, {42, 128, 64}, {43, 64, 64},
-                              {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256}};
+                              {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256},
+                              {91, 128, 128}, {92, 128, 64}, {93, 64, 64}, {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
+                              {52, 128, 128}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}, {45, 128, 128}, {53, 128, 128}};
 
+// Heuristic tile code for a shape (the default; the autotuner below and the debug hooks can replace it).
 template <int MODE>
-int launch(fie_ctx* ctx, GemmArgs& a) {
+int heuristic_code(const fie_ctx* ctx, const GemmArgs& a, bool dma_ok) {
     auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
     const int64_t cus = ctx->num_cus;
-    // LDS-DMA kernels (codes >= 40): 32-bit buffer offsets (operands < 2 GiB) and K-steps that never straddle a 3x3 tap / the A1|A2 seam
-    const bool dma_ok = a.a1_bytes < (1ll << 31) && a.a2_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) &&
-                        (MODE == 1 ? a.Cin % BK == 0 : (a.K1 == a.K || a.K1 % BK == 0));
     // Selection: tools/tile_table.py (interleaved rounds per shape, profiles/r02_tile_table.md) + tools/tile_trials.py inside the
     // UNet.  The K loop is paced by the per-CU global->LDS issue path (~100 cycles per 1 KiB piece), so a tile's FLOP per
     // staged byte BM*BN/(BM+BN) decides its ceiling -- but only while the grid still fills the CUs: the largest tile that does wins.
@@ -362,12 +457,12 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     } else {
         code = 43;
     }
-    int order = -1;                // 0: n-tiles fastest (an XCD owns a range of activation rows), 1: m-tiles fastest; -1: estimate below
-    for (int i = 0; i < ctx->n_overrides; ++i) {
-        const fie_tile_override& o = ctx->overrides[i];
-        if (o.mode == (MODE == 1) && o.M == a.M && o.N == a.N && o.K == a.K) { code = o.code % 1000; order = o.code >= 2000 ? 1 : o.code >= 1000 ? 0 : -1; }
-    }
-    if (ctx->force_tile) { code = ctx->force_tile % 1000; order = ctx->force_tile >= 2000 ? 1 : ctx->force_tile >= 1000 ? 0 : -1; }
+    return code;
+}
+
+// One launch of `code` (order: 0 n-tiles fastest, 1 m-tiles fastest, -1 estimate).
+template <int MODE>
+int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok) {
     const TileDim* t = nullptr;
     for (const TileDim& d : kTiles)
         if (d.code == code) t = &d;
@@ -398,7 +493,8 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     a.nbn = (a.N + t->bn - 1) / t->bn;
     a.order = order;
     a.probe = ctx->gemm_probe;
-    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 80 ? "gemm8_kernel" : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
+    a.stamps = (code == 97 || code == 98 || code == 94) ? ctx->gemm_stamps : nullptr;
+    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 90 ? "gemm3_kernel+prefetch" : code >= 80 ? "gemm8_kernel" : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
              t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
     if (a.w_scale) {
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "gemm3w8_kernel<%dx%d> (%s, fp8 weights, tile code %d)", t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
@@ -416,11 +512,118 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
         case 51: launch_ring<128, 128, 3, M3, 8>(ctx, a, grid); break;
         case 61: launch_ring<256, 256, 2, M3, 8>(ctx, a, grid); break;
         case 62: launch_ring<256, 128, 3, M3, 8>(ctx, a, grid); break;
+        case 52: launch_ring<128, 128, 2, M3, 8>(ctx, a, grid); break;
+        case 54: launch_ring<192, 128, 2, M3, 8>(ctx, a, grid); break;
+        case 46: launch_ring<64, 64, 2, M3, 4>(ctx, a, grid); break;
+        case 44: launch_ring<128, 64, 2, M3, 4>(ctx, a, grid); break;
+        case 45: launch_ring<128, 128, 2, M3, 4>(ctx, a, grid); break;
+        case 53: launch_ring<128, 128, 2, M3, 8, true>(ctx, a, grid); break;
+        case 91: launch_ring<128, 128, 3, M3, 4, true>(ctx, a, grid); break;
+        case 92: launch_ring<128, 64, 3, M3, 4, true>(ctx, a, grid); break;
+        case 93: launch_ring<64, 64, 3, M3, 4, true>(ctx, a, grid); break;
+        case 95: launch_ring<128, 128, 3, M3, 8, true>(ctx, a, grid); break;
+        case 96: launch_ring<256, 128, 3, M3, 8, true>(ctx, a, grid); break;
+        case 97: launch_ring<256, 128, 3, M3, 8, false, true>(ctx, a, grid); break;
+        case 98: launch_ring<256, 128, 3, M3, 8, true, true>(ctx, a, grid); break;
+        case 94: launch_ring<128, 64, 3, M3, 4, false, true>(ctx, a, grid); break;
         case 81: return fie_launch_gemm8(ctx, a, MODE == 1, 0);
         case 82: return fie_launch_gemm8(ctx, a, MODE == 1, 1);   // A/B: second DMA piece of a phase issued from inside the MFMA cluster (measured slower)
     }
     FIE_LAUNCH_CHECK();
     return FIE_OK;
+}
+
+// ---- per-shape autotune (fie_gemm_autotune): the first eager launch of a shape times every eligible tile on a scratch output
+// and remembers the fastest; later launches (and stream captures, which never tune) use the remembered code.  The candidates
+// differ in tile shape, ring depth and blocks per CU; every one accumulates K in the same order, so the choice does not change
+// the result.  Selection by measurement instead of by rule: which tile wins depends on how the grid quantises onto 256 CUs
+// and on whether two blocks share a CU (their epilogues and DMA issue overlap), see DESIGN.md.
+// Every timed launch sees what a launch inside the network sees: weights COLD (the 256 MB Infinity Cache is flushed by a
+// 384 MB memset; a UNet evaluation streams 2.6 GB of weights, so no layer finds its own in cache) and activations WARM (they
+// were just written by the previous layer; re-read here after the flush).  Timed warm, the two-stage tiles win almost
+// everywhere and then lose inside the network, where their one K-step of prefetch does not cover an HBM miss
+// (tools/cold_weights.py).
+constexpr size_t kFlushBytes = 384u << 20;
+
+template <int MODE>
+int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
+    static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81};
+    static const int kW8[] = {43, 42, 62};
+    const size_t bytes = (size_t)a.M * (size_t)a.ldc * sizeof(half_t);
+    if (bytes > ctx->tune_bytes) {
+        if (ctx->tune_buf) (void)hipFree(ctx->tune_buf);
+        ctx->tune_buf = nullptr;
+        ctx->tune_bytes = 0;
+        if (hipMalloc(&ctx->tune_buf, bytes) != hipSuccess) { (void)hipGetLastError(); return guess; }
+        ctx->tune_bytes = bytes;
+    }
+    if (!ctx->tune_flush && hipMalloc(&ctx->tune_flush, kFlushBytes) != hipSuccess) { (void)hipGetLastError(); ctx->tune_flush = nullptr; return guess; }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return guess;
+    (void)hipDeviceSynchronize();                          // nothing else on the device while the candidates are timed
+    GemmArgs t = a;
+    t.C = static_cast<half_t*>(ctx->tune_buf);           // a residual that aliases C is still read from the caller's buffer
+    auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+    auto time_of = [&](int code) -> float {
+        float ms[5];
+        for (int rep = -1; rep < 5; ++rep) {               // rep -1: untimed (first use of the kernel)
+            (void)hipMemsetAsync(ctx->tune_flush, rep & 1, kFlushBytes, ctx->stream);
+            if ((size_t)a.a1_bytes <= kFlushBytes) (void)hipMemcpyAsync(ctx->tune_flush, a.A1, (size_t)a.a1_bytes, hipMemcpyDeviceToDevice, ctx->stream);
+            if (a.A2 && a.A2 != a.A1 && (size_t)a.a2_bytes <= kFlushBytes) (void)hipMemcpyAsync(ctx->tune_flush, a.A2, (size_t)a.a2_bytes, hipMemcpyDeviceToDevice, ctx->stream);
+            (void)hipEventRecord(e0, ctx->stream);
+            if (run_code<MODE>(ctx, t, code, -1, dma_ok) != FIE_OK) return 1e30f;
+            (void)hipEventRecord(e1, ctx->stream);
+            if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+            if (rep >= 0) (void)hipEventElapsedTime(&ms[rep], e0, e1);
+        }
+        std::sort(ms, ms + 5);
+        return ms[2];
+    };
+    const float t_guess = time_of(guess);
+    int best = guess;
+    float t_best = t_guess * 0.97f;                          // a challenger has to win by 3 %
+    const int* cand = a.w_scale ? kW8 : kRing;
+    const int ncand = a.w_scale ? 3 : 9;
+    for (int i = 0; i < ncand; ++i) {
+        const int c = cand[i];
+        if (c == guess) continue;
+        if ((c == 43 || c == 46) && blocks(64, 64) > 64 * ctx->num_cus) continue;       // tens of thousands of tiny tiles: never wins
+        if ((c == 81 || c == 96 || c == 62) && 2 * blocks(256, 128) < ctx->num_cus) continue;
+        const float tc = time_of(c);
+        if (tc < t_best) { t_best = tc; best = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return best;
+}
+
+template <int MODE>
+int launch(fie_ctx* ctx, GemmArgs& a) {
+    // LDS-DMA kernels (codes >= 40): 32-bit buffer offsets (operands < 2 GiB) and K-steps that never straddle a 3x3 tap / the A1|A2 seam
+    const bool dma_ok = a.a1_bytes < (1ll << 31) && a.a2_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) &&
+                        (MODE == 1 ? a.Cin % BK == 0 : (a.K1 == a.K || a.K1 % BK == 0));
+    int code = heuristic_code<MODE>(ctx, a, dma_ok);
+    int order = -1;                // 0: n-tiles fastest (an XCD owns a range of activation rows), 1: m-tiles fastest; -1: estimate
+    bool pinned = false;
+    for (int i = 0; i < ctx->n_overrides; ++i) {
+        const fie_tile_override& o = ctx->overrides[i];
+        if (o.mode == (MODE == 1) && o.M == a.M && o.N == a.N && o.K == a.K) { code = o.code % 1000; order = o.code >= 2000 ? 1 : o.code >= 1000 ? 0 : -1; pinned = true; }
+    }
+    if (ctx->force_tile) { code = ctx->force_tile % 1000; order = ctx->force_tile >= 2000 ? 1 : ctx->force_tile >= 1000 ? 0 : -1; pinned = true; }
+    if (ctx->autotune && !pinned && dma_ok && !ctx->gemm_probe) {      // 1: tune shapes not met before, 2: remembered shapes only
+        const fie_tune_key key{MODE, a.M, a.N, a.K, a.K1, MODE == 1 ? a.stride * 2 + a.ups : 0, a.w_scale != nullptr};
+        auto it = ctx->tuned.find(key);
+        if (it != ctx->tuned.end()) {
+            code = it->second;
+        } else if (ctx->autotune == 1 && !ctx->recording) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+                code = autotune<MODE>(ctx, a, code, dma_ok);
+                ctx->tuned[key] = code;
+            }
+        }
+    }
+    return run_code<MODE>(ctx, a, code, order, dma_ok);
 }
 
 int check_epilogue(const char* who, int N, int64_t ldc, const void* res, int64_t ldr, int act) {
@@ -466,6 +669,20 @@ hipError_t ring_attrs() {
     if (e == hipSuccess) e = ring_attr<128, 128, 3, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<256, 256, 2, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<256, 128, 3, MODE, 8>();
+    if (e == hipSuccess) e = ring_attr<128, 128, 2, MODE, 8>();
+    if (e == hipSuccess) e = ring_attr<192, 128, 2, MODE, 8>();
+    if (e == hipSuccess) e = ring_attr<64, 64, 2, MODE, 4>();
+    if (e == hipSuccess) e = ring_attr<128, 64, 2, MODE, 4>();
+    if (e == hipSuccess) e = ring_attr<128, 128, 2, MODE, 4>();
+    if (e == hipSuccess) e = ring_attr<128, 128, 2, MODE, 8, true>();
+    if (e == hipSuccess) e = ring_attr<128, 128, 3, MODE, 4, true>();
+    if (e == hipSuccess) e = ring_attr<128, 64, 3, MODE, 4, true>();
+    if (e == hipSuccess) e = ring_attr<64, 64, 3, MODE, 4, true>();
+    if (e == hipSuccess) e = ring_attr<128, 128, 3, MODE, 8, true>();
+    if (e == hipSuccess) e = ring_attr<256, 128, 3, MODE, 8, true>();
+    if (e == hipSuccess) e = ring_attr<256, 128, 3, MODE, 8, false, true>();
+    if (e == hipSuccess) e = ring_attr<256, 128, 3, MODE, 8, true, true>();
+    if (e == hipSuccess) e = ring_attr<128, 64, 3, MODE, 4, false, true>();
     return e;
 }
 
@@ -506,8 +723,40 @@ int fie_debug_tile_override(fie_ctx* ctx, const char* spec) {
 }
 
 int fie_debug_gemm_probe(fie_ctx* ctx, int mode) {
-    FIE_REQUIRE(ctx != nullptr && mode >= 0 && mode <= 3, "fie_debug_gemm_probe: bad argument");
+    FIE_REQUIRE(ctx != nullptr && mode >= 0 && mode <= 4, "fie_debug_gemm_probe: bad argument");
     ctx->gemm_probe = mode;
+    return FIE_OK;
+}
+
+int fie_gemm_autotune(fie_ctx* ctx, int on) {
+    FIE_REQUIRE(ctx != nullptr && on >= 0 && on <= 2, "fie_gemm_autotune: bad argument");
+    ctx->autotune = on;
+    if (on != 1 && (ctx->tune_buf || ctx->tune_flush)) {   // the timing scratch is only needed while shapes are still being met
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->tune_buf) (void)hipFree(ctx->tune_buf);
+        if (ctx->tune_flush) (void)hipFree(ctx->tune_flush);
+        ctx->tune_buf = ctx->tune_flush = nullptr;
+        ctx->tune_bytes = 0;
+    }
+    return FIE_OK;
+}
+
+int fie_gemm_autotune_report(fie_ctx* ctx, char* buf, int cap) {
+    FIE_REQUIRE(ctx != nullptr && buf != nullptr && cap > 0, "fie_gemm_autotune_report: bad argument");
+    int n = 0;
+    buf[0] = 0;
+    for (const auto& kv : ctx->tuned) {
+        const fie_tune_key& k = kv.first;
+        const int w = snprintf(buf + n, (size_t)(cap - n), "%s M=%d N=%d K=%d K1=%d geom=%d w8=%d -> %d\n", k.mode ? "conv" : "gemm", k.M, k.N, k.K, k.K1, k.geom, k.w8, kv.second);
+        if (w < 0 || w >= cap - n) break;
+        n += w;
+    }
+    return (int)ctx->tuned.size();
+}
+
+int fie_debug_gemm_stamps(fie_ctx* ctx, void* buf) {
+    FIE_REQUIRE(ctx != nullptr, "fie_debug_gemm_stamps: NULL ctx");
+    ctx->gemm_stamps = static_cast<unsigned*>(buf);
     return FIE_OK;
 }
 

@@ -75,7 +75,10 @@ SIGNATURES = {
     "fie_debug_gn_onepass": [_I],
     "fie_debug_tile_override": [_P, _c.c_char_p],
     "fie_debug_last_gemm_kernel": [_P],
+    "fie_gemm_autotune": [_P, _I],
+    "fie_gemm_autotune_report": [_P, ctypes.c_char_p, _I],
     "fie_debug_gemm_probe": [_P, _I],
+    "fie_debug_gemm_stamps": [_P, _P],
 }
 
 _lib = None
@@ -232,6 +235,19 @@ class Context:
     def force_tile(self, code):
         """0 = heuristic; see include/fie.h for the codes.  An ineligible code makes the op raise FieError."""
         _chk(lib().fie_debug_force_tile(self.h, int(code)))
+
+    def autotune(self, on=True):
+        """Per-shape tile autotune (include/fie.h: fie_gemm_autotune): first eager launch of a shape times the eligible tiles."""
+        _chk(lib().fie_gemm_autotune(self.h, int(on)))                # 0 off, 1 tune new shapes, 2 remembered shapes only
+
+    def autotune_report(self):
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = lib().fie_gemm_autotune_report(self.h, buf, len(buf))
+        return n, buf.value.decode()
+
+    def gemm_stamps(self, buf):
+        """Device int32 tensor [tiles * waves * 8] the stamped ring kernels (tile codes 97 / 98) write their cycle sums to; None detaches."""
+        _chk(lib().fie_debug_gemm_stamps(self.h, buf.data_ptr() if buf is not None else None))
 
     def gemm_probe(self, mode):
         """TIMING-ONLY probes of the LDS-DMA GEMM kernels (outputs are wrong): 0 off, 1 loads dropped, 2 all tiles load tile (0,0)."""

@@ -49,6 +49,10 @@ class HipImg2ImgPipeline:
         self.last_stats = {}
         self.timing = None         # set to [] to collect per-stage HIP-event timings in run_device()
         self.use_graph = os.environ.get("FIE_NO_GRAPH", "0") != "1"
+        # GEMM / conv tile selection by measurement: the eager warm-up in front of every capture meets each shape once
+        # (include/fie.h: fie_gemm_autotune); FIE_AUTOTUNE=0 keeps the built-in rule
+        self.autotune = ctx.device.type == "cuda" and os.environ.get("FIE_AUTOTUNE", "1") != "0"
+        ctx.autotune(2 if self.autotune else 0)     # shapes are tuned during the eager warm-up of a capture only (_capture)
         # hipGraph cache, bounded: key = (size, CFG batch, step plan, guidance, control scale, slot, images); at most MAX_GRAPHS
         # keys are captured (insertion-ordered dict, least recently used first); a key beyond the cap runs EAGERLY instead of
         # evicting -- destroying a graph and capturing another one was measured to give a slow graph (121 vs 81 ms), and a
@@ -318,8 +322,10 @@ class HipImg2ImgPipeline:
         static["t_dev"] = [t.clone() for t in job["t_dev"]]
         timing, self.timing = self.timing, None
         self.ctx.ws_tag = slot
-        self.run_device(static)                     # eager warm-up: lazy workspaces / function attributes
+        self.ctx.autotune(1 if self.autotune else 0)
+        self.run_device(static)                     # eager warm-up: lazy workspaces / function attributes, tile autotune
         torch.cuda.synchronize()
+        self.ctx.autotune(2 if self.autotune else 0)   # frees the tuner's scratch; the capture below uses what it remembered
         graph = torch.cuda.CUDAGraph()
         pool = self._pools.get(slot)
         if pool is None:

@@ -227,7 +227,17 @@ int fie_lcm_step_f32(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, floa
  * + 1000 / + 2000: force n-tiles / m-tiles fastest tile order (plain codes estimate the order that re-streams fewer bytes).  A code the shape is not eligible for returns FIE_EINVAL from the op. */
 int fie_debug_force_tile(fie_ctx* ctx, int tile);                  /* 0 = heuristic */
 int fie_debug_tile_override(fie_ctx* ctx, const char* spec);       /* "mode,M,N,K=code;..." (mode 0 GEMM, 1 conv); NULL clears; returns the count */
-int fie_debug_gemm_probe(fie_ctx* ctx, int mode);                  /* TIMING-ONLY probes of the LDS-DMA kernels (outputs are wrong): 0 off, 1 = DMA loads dropped by the descriptor, 2 = every tile loads tile (0,0), 3 = ring kernels: no DMA issued in the K loop */
+/* Per-shape tile autotune.  on = 1: the first EAGER launch of every GEMM / 3x3-conv problem (M, N, K, geometry, weight type) times
+ * the eligible tile kernels on a scratch output (the caller's C is written once, by the winner), each launch with the weights
+ * cold (a 384 MB flush) and the activations warm, as a layer inside the network sees them, and the context remembers the
+ * fastest; launches under stream capture or program recording never tune, they use what is remembered, else the built-in rule.
+ * Every tile accumulates K in the same order, so the choice does not change results.  on = 2 keeps using what is remembered but
+ * tunes nothing new and frees the scratch (0.4 GB + one output); on = 0 returns to the built-in rule.  fie_gemm_autotune_report writes one "gemm|conv M= N= K= K1= geom= w8= -> code" line per remembered problem
+ * into buf (NUL-terminated, truncated to cap) and returns the number of problems. */
+int fie_gemm_autotune(fie_ctx* ctx, int on);
+int fie_gemm_autotune_report(fie_ctx* ctx, char* buf, int cap);
+int fie_debug_gemm_probe(fie_ctx* ctx, int mode);                  /* TIMING-ONLY probes of the LDS-DMA kernels (outputs are wrong): 0 off, 1 = DMA loads dropped by the descriptor, 2 = every tile loads tile (0,0), 3 = ring kernels: no DMA issued in the K loop, 4 = no epilogue */
+int fie_debug_gemm_stamps(fie_ctx* ctx, void* buf);                  /* device buffer for the stamped ring kernels (tile codes 97 / 98): per tile and wave 8 uint32 cycle sums -- [0] drain + barrier, [1]/[4] DMA issue, [2]/[5] fragment reads, [3]/[6] MFMA issue (code 98: [0] = whole K-steps); NULL detaches */
 const char* fie_debug_last_gemm_kernel(fie_ctx* ctx);              /* kernel / tile of the last fie_gemm_f16 / fie_conv3x3_nhwc_f16 launch */
 int fie_debug_attn_variant(int variant);   /* 0 = default kernel, 1 = first-generation kernel (A/B benchmarking) */
 int fie_debug_gn_onepass(int enable);      /* 1 = default (single-pass GroupNorm on small maps), 0 = always partial/finalize/apply */

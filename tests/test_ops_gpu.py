@@ -240,7 +240,7 @@ def test_clip_embed(fie):
     assert rel_err(out, ref) < 2e-3
 
 
-@pytest.mark.parametrize("code", [1, 2, 3, 41, 42, 43, 51, 61, 62, 81, 82, 1042, 2042, 1062, 2081])
+@pytest.mark.parametrize("code", [1, 2, 3, 41, 42, 43, 51, 61, 62, 81, 82, 91, 92, 93, 95, 96, 44, 45, 46, 52, 53, 54, 1042, 2042, 1062, 2081])
 def test_gemm_conv_every_shipped_kernel(fie, code):
     """Every kernel / tile the launch table can select (gemm_conv.hip kTiles; + 2000 = m-tiles-fastest order) gives the
     reference result on GEMMs with ragged M / N / K tails and on convs with stride 2, asymmetric pad and fused upsample; a
@@ -418,6 +418,52 @@ def test_tile_override_steers_one_shape(fie):
         assert fie.tile_override(None) == 0
     assert rel_err(out, ref.float()) < 2e-3 and rel_err(other, ref[:256].float()) < 2e-3
     assert rel_err(ref, a.float() @ w.float().T + bias.float()) < 3e-3
+
+
+def test_gemm_autotune_picks_by_measurement_and_keeps_results(fie):
+    """fie_gemm_autotune (include/fie.h): the first eager launch of a shape times the eligible tiles (weights flushed cold) and
+    the context remembers one; results are bit-identical to the built-in rule's (every tile accumulates K in the same order), an
+    in-place residual (res == C) survives the timing launches (they write a scratch output), a stream capture never tunes,
+    mode 2 keeps the remembered code without tuning new shapes, mode 0 returns to the rule."""
+    from fie_amd import hip
+    m, n, k = 2048, 1280, 640
+    a, w, bias = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5), rnd(n, seed=3)
+    ad, bd = a.to(DEV), bias.to(DEV)
+    wp = fie.pack_linear(w.to(DEV))
+    x = rnd(2, 32, 32, 128, seed=4).to(DEV)
+    wc = fie.pack_conv3x3(rnd(256, 128, 3, 3, seed=5, scale=(9 * 128) ** -0.5).to(DEV))
+    res0 = rnd(m, n, seed=6).to(DEV)
+    ref = fie.gemm(ad, wp, n, bias=bd).clone()
+    ref_res = fie.gemm(ad, wp, n, bias=bd, residual=res0, out=res0.clone()).clone()
+    ref_conv = fie.conv3x3(x, wc, 256).clone()
+    rule_kernel = hip.last_gemm_kernel(fie)
+    try:
+        fie.autotune(1)
+        inplace = res0.clone()
+        got_res = fie.gemm(ad, wp, n, bias=bd, residual=inplace, out=inplace).clone()      # tuned on this call
+        got = fie.gemm(ad, wp, n, bias=bd).clone()
+        got_conv = fie.conv3x3(x, wc, 256).clone()
+        count, report = fie.autotune_report()
+        assert count == 2 and f"gemm M={m} N={n} K={k}" in report and "conv M=2048 N=256 K=1152" in report
+        assert torch.equal(got, ref) and torch.equal(got_res, ref_res) and torch.equal(got_conv, ref_conv)
+        fie.autotune(2)                                                                     # frozen: a new shape is not tuned
+        fie.gemm(ad[:512], wp, n, bias=bd)
+        assert fie.autotune_report()[0] == 2
+        fie.autotune(1)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            small = ad[:1024].clone()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                cap = fie.gemm(small, wp, n, bias=bd)                                      # unseen shape under capture: rule, not tuned
+            g.replay()
+        torch.cuda.synchronize()
+        assert fie.autotune_report()[0] == 2 and torch.equal(cap, ref[:1024])
+    finally:
+        fie.autotune(0)
+    fie.conv3x3(x, wc, 256)
+    assert hip.last_gemm_kernel(fie) == rule_kernel
 
 
 def test_time_embed_fused(fie):

@@ -34,7 +34,7 @@ else:
 for code in codes:
     ctx.force_tile(code)
     row = []
-    for probe, tag in ((0, "normal"), (2, "all-L2-hit"), (1, "loads-dropped"), (3, "no-DMA-issue")):
+    for probe, tag in ((0, "normal"), (2, "all-L2-hit"), (1, "loads-dropped"), (3, "no-DMA-issue"), (4, "no-epilogue")):
         ctx.gemm_probe(probe)
         dt = min(timeit(fn, iters=20) for _ in range(3))
         row.append(f"{tag}: {dt * 1e6:8.1f} us {fl / dt / 1e12:7.1f} TF")
