@@ -248,7 +248,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();                      // pairs with group 1's last barrier
 
-    epilogue<8, 4, 128, 64>(p, acc, m0, n0, wm, wn, lane);
+    // two column halves: with all 32 fragments in one pass the epilogue's temporaries do not fit beside 128 accumulator registers
+    epilogue<8, 2, 128, 64, true>(p, reinterpret_cast<f32x4(&)[2][8]>(acc[0]), m0, n0, wm, wn, lane);
+    epilogue<8, 2, 128, 64, true>(p, reinterpret_cast<f32x4(&)[2][8]>(acc[2]), m0, n0 + 32, wm, wn, lane);
 }
 
 constexpr int kLds8 = 2 * BUFH * (int)sizeof(half_t);               // 128 KiB

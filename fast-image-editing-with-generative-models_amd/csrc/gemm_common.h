@@ -37,61 +37,136 @@ struct GemmArgs {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
 
-template <int FM, int FN, int WM, int WN>
+// Epilogue: bias / row bias / activation / scale / residual on the fp32 accumulators, then f16 stores.
+// Shape of the code matters here: written as ONE loop over the fragments with every option tested per fragment it compiled to
+// ~100 scalar branches, 64-bit address arithmetic per access and a load -> vmcnt(0) -> use chain per fragment (vmcnt counts the
+// earlier fragments' stores as well): 13-30 % of a kernel's time (tools/gemm_probe.py, probe 4).  Now a few straight-line sweeps
+// over the accumulators, one per optional term behind one uniform branch each, and with BUF (the LDS-DMA kernels; C / residual
+// spans <= 1 GiB, checked by the launcher) every access is a buffer instruction on a 32-bit offset: lanes outside the matrix
+// take an out-of-range offset and the descriptor's range check drops them, so there are no masks or branches at all.
+// The MFMA layout gives a lane 4 consecutive columns of one row (8-B stores, 32 B per row and instruction); transposing the
+// tile through LDS into full-row 16-B stores was built and measured equal (+-3 %) once the code above was lean, so it is not here.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int FM, int FN, int WM, int WN, bool BUF = false>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     if (p.probe == 4 && p.M > 0) return;                    // timing probe: no epilogue at all (p.M > 0 keeps the accumulators live)
-    // ---- epilogue: lane holds C[m = .. + fr][n = .. + fq*4 + (0..3)]
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-        const int m = m0 + wm * WM + j * 16 + fr;
-        if (m >= p.M) continue;
-        const half_t* rb = nullptr;
-        if (p.rowbias) rb = p.rowbias + (int64_t)(m / p.rows_per_batch) * p.ld_rowbias;
+    const bool geglu = p.act == FIE_ACT_GEGLU;
+    const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
+    // clamped coordinates for the loads of the pointer form; BUF: byte offsets, out of range where the lane is outside the matrix
+    auto col = [&](int i) { const int n = ncol + i * 16; return n < p.N ? n : p.N - 4; };       // N % 4 == 0
+    auto row = [&](int j) { const int m = mrow + j * 16; return m < p.M ? m : p.M - 1; };
+    constexpr unsigned kRowOut = 0x80000000u, kColOut = 0xC0000000u;    // any sum with a span <= 1 GiB stays out of range
+    auto coff = [&](int i, bool half) { const int n = ncol + i * 16; return n < p.N ? (unsigned)n << (half ? 0 : 1) : kColOut; };   // bytes; half (GEGLU): output column n / 2
+    auto roff = [&](int j, int64_t ld) { const int m = mrow + j * 16; return m < p.M ? (unsigned)m * (unsigned)ld * 2u : kRowOut; };
+    auto rsrc = [&](const void* ptr, int64_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000); };
+    auto as_h4 = [](u32x2 v) { f16x4 h; __builtin_memcpy(&h, &v, 8); return h; };
+
+    if (p.w_scale) {
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
-            const int n = n0 + wn * WN + i * 16 + fq * 4;
-            if (n >= p.N) continue;
-            f32x4 v = acc[i][j];
-            if (p.w_scale) {
-                const float4 ws = *reinterpret_cast<const float4*>(p.w_scale + n);
-                v[0] *= ws.x; v[1] *= ws.y; v[2] *= ws.z; v[3] *= ws.w;
-            }
-            if (p.bias) {
-                const f16x4 b = *reinterpret_cast<const f16x4*>(p.bias + n);
+            const float4 ws = *reinterpret_cast<const float4*>(p.w_scale + col(i));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
-            }
-            if (rb) {
-                const f16x4 b = *reinterpret_cast<const f16x4*>(rb + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
-            }
-            if (p.act == FIE_ACT_GEGLU) {
-                f16x2 o;
-                o[0] = (half_t)(v[0] * fie_gelu(v[1]) * p.scale);
-                o[1] = (half_t)(v[2] * fie_gelu(v[3]) * p.scale);
-                *reinterpret_cast<f16x2*>(p.C + (int64_t)m * p.ldc + (n >> 1)) = o;
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = v[r];
-                if (p.act == FIE_ACT_SILU) x = fie_silu(x);
-                else if (p.act == FIE_ACT_GELU) x = fie_gelu(x);
-                else if (p.act == FIE_ACT_QUICK_GELU) x = fie_qgelu(x);
-                v[r] = x * p.scale;
-            }
-            if (p.res) {
-                const f16x4 b = *reinterpret_cast<const f16x4*>(p.res + (int64_t)m * p.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
-            }
-            f16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-            *reinterpret_cast<f16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+            for (int j = 0; j < FM; ++j) { acc[i][j][0] *= ws.x; acc[i][j][1] *= ws.y; acc[i][j][2] *= ws.z; acc[i][j][3] *= ws.w; }
         }
+    }
+    if (p.bias) {
+        f16x4 b[FN];
+#pragma unroll
+        for (int i = 0; i < FN; ++i) b[i] = *reinterpret_cast<const f16x4*>(p.bias + col(i));
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)b[i][r];
+    }
+    if (p.rowbias) {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const half_t* rb = p.rowbias + (int64_t)(row(j) / p.rows_per_batch) * p.ld_rowbias;
+            f16x4 b[FN];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) b[i] = *reinterpret_cast<const f16x4*>(rb + col(i));
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)b[i][r];
+        }
+    }
+    auto sweep = [&](auto f) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = f(acc[i][j][r]) * p.scale;
+    };
+    if (geglu) {                                            // (value, gate) column pairs -> acc[.][.][0..1]
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                acc[i][j][0] = acc[i][j][0] * fie_gelu(acc[i][j][1]) * p.scale;
+                acc[i][j][1] = acc[i][j][2] * fie_gelu(acc[i][j][3]) * p.scale;
+            }
+    } else if (p.act == FIE_ACT_SILU) sweep([](float x) { return fie_silu(x); });
+    else if (p.act == FIE_ACT_GELU) sweep([](float x) { return fie_gelu(x); });
+    else if (p.act == FIE_ACT_QUICK_GELU) sweep([](float x) { return fie_qgelu(x); });
+    else if (p.scale != 1.f) sweep([](float x) { return x; });
+    if (p.res) {                                            // never with GEGLU (check_epilogue); may alias C: read before this tile's stores
+        const __amdgpu_buffer_rsrc_t rs = rsrc(p.res, BUF ? ((int64_t)(p.M - 1) * p.ldr + p.N) * 2 : 0);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            f16x4 b[FN];
+            if constexpr (BUF) {
+                const unsigned ro = roff(j, p.ldr);
+#pragma unroll
+                for (int i = 0; i < FN; ++i) b[i] = as_h4(__builtin_amdgcn_raw_buffer_load_b64(rs, ro + coff(i, false), 0, 0));
+            } else {
+                const half_t* rr = p.res + (int64_t)row(j) * p.ldr;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) b[i] = *reinterpret_cast<const f16x4*>(rr + col(i));
+            }
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)b[i][r];
+            if (FM * FN > 16) __builtin_amdgcn_sched_barrier(0);        // 256x256: no room to keep every row's loads in flight
+        }
+    }
+    // ---- stores: lane holds C[m = .. + fr][n = .. + fq*4 + (0..3)]
+    const __amdgpu_buffer_rsrc_t rs_c = rsrc(p.C, BUF ? ((int64_t)(p.M - 1) * p.ldc + (geglu ? p.N >> 1 : p.N)) * 2 : 0);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = mrow + j * 16;
+        const unsigned ro = roff(j, p.ldc);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int n = ncol + i * 16;
+            if (geglu) {
+                f16x2 o;
+                o[0] = (half_t)acc[i][j][0]; o[1] = (half_t)acc[i][j][1];
+                if constexpr (BUF) {
+                    unsigned bits; __builtin_memcpy(&bits, &o, 4);
+                    __builtin_amdgcn_raw_buffer_store_b32(bits, rs_c, ro + coff(i, true), 0, 0);
+                } else if (m < p.M && n < p.N) {
+                    *reinterpret_cast<f16x2*>(p.C + (int64_t)m * p.ldc + (n >> 1)) = o;
+                }
+            } else {
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)acc[i][j][r];
+                if constexpr (BUF) {
+                    u32x2 bits; __builtin_memcpy(&bits, &o, 8);
+                    __builtin_amdgcn_raw_buffer_store_b64(bits, rs_c, ro + coff(i, false), 0, 0);
+                } else if (m < p.M && n < p.N) {
+                    *reinterpret_cast<f16x4*>(p.C + (int64_t)m * p.ldc + n) = o;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // one row of fragments at a time: converting all of them first costs 2 VGPRs each (256x256: spills)
     }
 }
 

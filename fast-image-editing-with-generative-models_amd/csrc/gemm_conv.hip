@@ -383,7 +383,13 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         fill = fill + 1 == ST ? 0 : fill + 1;
     }
     stamp(11);                                             // last MFMA group issued
-    epilogue<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+    if constexpr (FM * FN > 16) {                          // 256x256: two column halves, see gemm8.hip
+        static_assert(FN == 4, "");
+        epilogue<FM, 2, WM, WN, true>(p, reinterpret_cast<f32x4(&)[2][FM]>(acc[0]), m0, n0, wm, wn, lane);
+        epilogue<FM, 2, WM, WN, true>(p, reinterpret_cast<f32x4(&)[2][FM]>(acc[2]), m0, n0 + 32, wm, wn, lane);
+    } else {
+        epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane);
+    }
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's stores have left the wave
         stamp(8);
@@ -600,7 +606,9 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
 template <int MODE>
 int launch(fie_ctx* ctx, GemmArgs& a) {
     // LDS-DMA kernels (codes >= 40): 32-bit buffer offsets (operands < 2 GiB) and K-steps that never straddle a 3x3 tap / the A1|A2 seam
-    const bool dma_ok = a.a1_bytes < (1ll << 31) && a.a2_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) &&
+    // ... and an epilogue on 32-bit buffer offsets (gemm_common.h): output / residual spans of at most 1 GiB
+    const int64_t c_span = ((int64_t)(a.M - 1) * a.ldc + a.N) * 2, r_span = a.res ? ((int64_t)(a.M - 1) * a.ldr + a.N) * 2 : 0;
+    const bool dma_ok = a.a1_bytes < (1ll << 31) && a.a2_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) && c_span <= (1ll << 30) && r_span <= (1ll << 30) &&
                         (MODE == 1 ? a.Cin % BK == 0 : (a.K1 == a.K || a.K1 % BK == 0));
     int code = heuristic_code<MODE>(ctx, a, dma_ok);
     int order = -1;                // 0: n-tiles fastest (an XCD owns a range of activation rows), 1: m-tiles fastest; -1: estimate

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3w8_kernel(GemmArgs p) {
         stage = stage + 1 == ST ? 0 : stage + 1;
         fill = fill + 1 == ST ? 0 : fill + 1;
     }
-    epilogue<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);       // p.w_scale: acc *= scale[n] first
+    epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane);       // p.w_scale: acc *= scale[n] first
 }
 
 template <int BM, int BN, int ST>
