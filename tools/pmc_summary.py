@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Average the counters of `rocprofv3 --pmc ... --output-format csv` passes over the launches of ONE kernel and write the
 record bench.py reads for `roofline.traffic` (profiles/dominant_kernel_pmc.json).
-usage: tools/pmc_summary.py <kernel-name substring> M N K out.json <pass dir> [<pass dir> ...]"""
+usage: tools/pmc_summary.py <kernel-name substring> M N K out.json <pass dir> [<pass dir> ...]
+With FIE_PMC_TILE=<code> in the environment the record is filed under records[<code>] of out.json (one record per tile code
+the autotuner may pick for the shape); without it out.json is the single record."""
 import csv
 import glob
 import json
@@ -36,5 +38,16 @@ if "SQ_WAVE_CYCLES" in c:
             rec[name.lower() + "_frac"] = round(c[name] / c["SQ_WAVE_CYCLES"], 4)
 if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
     rec["mfma_pipe_utilisation"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 4)   # busy cycles / (cycles per XCD x 1024 SIMDs)
-json.dump(rec, open(out, "w"), indent=1)
+tile = os.environ.get("FIE_PMC_TILE")
+if tile:
+    rec["tile_code"] = int(tile)
+    doc = {"shape": rec["shape"], "records": {}}
+    if os.path.exists(out):
+        old = json.load(open(out))
+        if old.get("shape") == rec["shape"] and "records" in old:
+            doc = old
+    doc["records"][tile] = rec
+    json.dump(doc, open(out, "w"), indent=1)
+else:
+    json.dump(rec, open(out, "w"), indent=1)
 print(json.dumps({k_: v for k_, v in rec.items() if k_ != "source"}, indent=1))
