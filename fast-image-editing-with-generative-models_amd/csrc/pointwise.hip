@@ -294,7 +294,24 @@ int lcm_step_t(fie_ctx* ctx, const void* eps, int64_t ld_eps, int nb, float guid
 
 }  // namespace
 
+// One dword of every 128-B line of [p, p + bytes): pulls the range from HBM into the Infinity Cache (and this XCD's L2) ahead of the
+// kernel that will stream it.  The loads are never consumed; the asm keeps them.
+__global__ __launch_bounds__(256) void prefetch_kernel(const unsigned* p, size_t lines) {
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < lines; i += (size_t)gridDim.x * 256) acc += p[i * 32];
+    asm volatile("" ::"v"(acc));
+}
+
 extern "C" {
+
+int fie_prefetch(fie_ctx* ctx, const void* ptr, int64_t bytes, void* stream, int blocks) {
+    FIE_REQUIRE(ctx && ptr && bytes > 0 && blocks > 0 && blocks <= 4096, "fie_prefetch: bad argument");
+    const size_t lines = (size_t)bytes / 128;
+    if (lines == 0) return FIE_OK;
+    hipLaunchKernelGGL(prefetch_kernel, dim3((unsigned)blocks), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream, (const unsigned*)ptr, lines);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
 
 int fie_sinusoid_f16(fie_ctx* ctx, const float* vals, int B, int nvals, int dim, void* out, int64_t ld_out, int col0) {
     return sinusoid_t<half_t>(ctx, vals, B, nvals, dim, out, ld_out, col0);

@@ -75,6 +75,7 @@ SIGNATURES = {
     "fie_debug_gn_onepass": [_I],
     "fie_debug_tile_override": [_P, _c.c_char_p],
     "fie_debug_last_gemm_kernel": [_P],
+    "fie_prefetch": [_P, _P, _L, _P, _I],
     "fie_gemm_autotune": [_P, _I],
     "fie_gemm_autotune_report": [_P, ctypes.c_char_p, _I],
     "fie_debug_gemm_probe": [_P, _I],
@@ -235,6 +236,10 @@ class Context:
     def force_tile(self, code):
         """0 = heuristic; see include/fie.h for the codes.  An ineligible code makes the op raise FieError."""
         _chk(lib().fie_debug_force_tile(self.h, int(code)))
+
+    def prefetch(self, t, stream=None, blocks=16):
+        """Pull tensor t (a packed weight) into the Infinity Cache on `stream` (a torch stream; default: the context's)."""
+        _chk(lib().fie_prefetch(self.h, t.data_ptr(), t.numel() * t.element_size(), stream.cuda_stream if stream is not None else None, int(blocks)))
 
     def autotune(self, on=True):
         """Per-shape tile autotune (include/fie.h: fie_gemm_autotune): first eager launch of a shape times the eligible tiles."""

@@ -234,6 +234,9 @@ int fie_debug_tile_override(fie_ctx* ctx, const char* spec);       /* "mode,M,N,
  * Every tile accumulates K in the same order, so the choice does not change results.  on = 2 keeps using what is remembered but
  * tunes nothing new and frees the scratch (0.4 GB + one output); on = 0 returns to the built-in rule.  fie_gemm_autotune_report writes one "gemm|conv M= N= K= K1= geom= w8= -> code" line per remembered problem
  * into buf (NUL-terminated, truncated to cap) and returns the number of problems. */
+/* Touches one dword of every 128-byte line of [ptr, ptr + bytes) with `blocks` small workgroups on `stream` (NULL: the context's): pulls a
+ * weight matrix from HBM into the Infinity Cache ahead of the kernel that will stream it.  Reads only; no result. */
+int fie_prefetch(fie_ctx* ctx, const void* ptr, int64_t bytes, void* stream, int blocks);
 int fie_gemm_autotune(fie_ctx* ctx, int on);
 int fie_gemm_autotune_report(fie_ctx* ctx, char* buf, int cap);
 int fie_debug_gemm_probe(fie_ctx* ctx, int mode);                  /* TIMING-ONLY probes of the LDS-DMA kernels (outputs are wrong): 0 off, 1 = DMA loads dropped by the descriptor, 2 = every tile loads tile (0,0), 3 = ring kernels: no DMA issued in the K loop, 4 = no epilogue */
