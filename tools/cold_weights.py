@@ -39,7 +39,7 @@ def main():
         ws = [ctx.pack_linear(torch.randn(n, k, device=DEV, dtype=torch.float16) * k ** -0.5) for _ in range(copies)]
         out = torch.empty(m, n, device=DEV, dtype=torch.float16)
         cases.append((f"gemm M={m} N={n} K={k} ({copies} copies)", [lambda w=w, a=a, n=n, out=out: ctx.gemm(a, w, n, out=out) for w in ws], 2.0 * m * n * k))
-    for b, h, cin, cout in [(2, 32, 1280, 1280), (2, 32, 2560, 1280), (2, 64, 640, 640), (2, 64, 1280, 640), (2, 128, 320, 320)]:
+    for b, h, cin, cout in [(2, 32, 640, 1280), (2, 32, 1280, 1280), (2, 32, 1920, 1280), (2, 32, 2560, 1280), (2, 64, 640, 640), (2, 64, 1280, 640), (2, 128, 320, 320)]:
         copies = max(2, int(600e6 / (cout * cin * 18)) + 1)
         x = torch.randn(b, h, h, cin, device=DEV, dtype=torch.float16)
         ws = [ctx.pack_conv3x3(torch.randn(cout, cin, 3, 3, device=DEV, dtype=torch.float16) * (9 * cin) ** -0.5) for _ in range(copies)]
