@@ -51,6 +51,9 @@ struct fie_ctx {
     int force_tile = 0;
     int gemm_probe = 0;
     unsigned* gemm_stamps = nullptr;
+    float* gn_target = nullptr;              // fie_gn_stats_target: consumed by the next GEMM / conv launch
+    int64_t gn_target_rows = 0;
+    int gn_target_groups = 0;
     int autotune = 0;                        // fie_gemm_autotune: time the eligible tiles at a shape's first eager launch
     std::map<fie_tune_key, int> tuned;
     void* tune_buf = nullptr;                // scratch output of the timing launches

@@ -29,6 +29,7 @@ struct GemmArgs {
     float scale; int act;
     int nbm, nbn;
     int64_t a1_bytes, a2_bytes, w_bytes;   // operand extents for the v3 buffer descriptors
+    float* gn_partial; int gn_rows, gn_G, gn_cg;   // GroupNorm statistics of the OUTPUT (fie_gn_stats_target): per image and 32-row granule [b][gn_rows / 32][gn_G][2] = (sum, sum of squares) of the f16-rounded values, gn_cg = N / gn_G in {4, 8, 16} channels per group; NULL: none
     const float* w_scale;                   // fp8 weights (gemm_w8.hip): per-output-channel dequantisation scale [N], applied to the accumulator first; Wt then points at e4m3 bytes and ldw counts bytes
     unsigned* stamps;                       // tile codes 97 / 98: [tile][wave][8] cycle sums of the K-loop segments (fie_debug_gemm_stamps), else NULL
     int probe;                              // timing-only probes (fie_debug_gemm_probe; outputs are wrong): 1 = every DMA load dropped (zero-record descriptors), 2 = every tile fetches tile (0,0)'s operands (all L2 hits), 3 = ring kernels issue no DMA inside the K loop (MFMA + ds_read + barrier floor), 4 = no epilogue (nothing stored)
@@ -47,6 +48,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + (
 // The MFMA layout gives a lane 4 consecutive columns of one row (8-B stores, 32 B per row and instruction); transposing the
 // tile through LDS into full-row 16-B stores was built and measured equal (+-3 %) once the code above was lean, so it is not here.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k + 15), result in every lane: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
 
 template <int FM, int FN, int WM, int WN, bool BUF = false>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane) {
@@ -134,6 +144,56 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)b[i][r];
             if (FM * FN > 16) __builtin_amdgcn_sched_barrier(0);        // 256x256: no room to keep every row's loads in flight
+        }
+    }
+    if (p.gn_partial) {
+        // GroupNorm partial sums of what is about to be stored (the consumer normalises the f16 tensor, so the sums run over the
+        // ROUNDED values): a lane's 4 columns lie in one group (cg = 4: are one group); rows reduce over the 16 fr lanes and over the
+        // two fragments of a 32-row granule, columns over 1 / 2 / 4 fq lanes.  One lane per (granule, group) stores: every slot has
+        // exactly one writer, so the sums are deterministic.  WM % 32 == 0 for every tile.
+        static_assert(FM % 2 == 0, "row granules are two fragments");
+        const int nch = p.gn_rows >> 5;
+#pragma unroll
+        for (int jj = 0; jj < FM / 2; ++jj) {
+            float sum[FN], sq[FN];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) sum[i] = sq[i] = 0.f;
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                const bool ok = mrow + (2 * jj + dj) * 16 < p.M;
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = ok ? (float)(half_t)acc[i][2 * jj + dj][r] : 0.f;
+                        sum[i] += x;
+                        sq[i] += x * x;
+                    }
+            }
+            const int mg = m0 + wm * WM + jj * 32;          // first row of the granule (wave-uniform)
+            const int b = mg / p.gn_rows, chunk = (mg - b * p.gn_rows) >> 5;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                // 16 rows: four DPP adds (xor 1, xor 2, mirror in 8, mirror in 16) leave the row-of-16 total in every lane, VALU only;
+                // the four fq totals are then read as scalars from lanes 0 / 16 / 32 / 48
+                const float rs = row16_sum(sum[i]), rq = row16_sum(sq[i]);
+                float ts[4], tq[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ts[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), 16 * k));
+                    tq[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rq), 16 * k));
+                }
+                if (p.gn_cg == 16) { ts[0] = (ts[0] + ts[1]) + (ts[2] + ts[3]); tq[0] = (tq[0] + tq[1]) + (tq[2] + tq[3]); }
+                else if (p.gn_cg == 8) { ts[0] += ts[1]; tq[0] += tq[1]; ts[1] = ts[2] + ts[3]; tq[1] = tq[2] + tq[3]; }
+                const int ngrp = 16 / p.gn_cg;                // groups in this fragment's 16 columns: 1, 2 or 4
+                const int nfrag = n0 + wn * WN + i * 16;      // wave-uniform
+                if (lane < ngrp && mg < p.M && nfrag + lane * p.gn_cg < p.N) {
+                    const float vs = lane == 0 ? ts[0] : lane == 1 ? ts[1] : lane == 2 ? ts[2] : ts[3];
+                    const float vq = lane == 0 ? tq[0] : lane == 1 ? tq[1] : lane == 2 ? tq[2] : tq[3];
+                    float2* dst = reinterpret_cast<float2*>(p.gn_partial) + ((int64_t)b * nch + chunk) * p.gn_G + nfrag / p.gn_cg + lane;
+                    *dst = make_float2(vs, vq);
+                }
+            }
         }
     }
     // ---- stores: lane holds C[m = .. + fr][n = .. + fq*4 + (0..3)]

@@ -736,6 +736,14 @@ int fie_debug_gemm_probe(fie_ctx* ctx, int mode) {
     return FIE_OK;
 }
 
+int fie_gn_stats_target(fie_ctx* ctx, void* partial, int64_t rows_per_image, int groups) {
+    FIE_REQUIRE(ctx != nullptr && (partial == nullptr || (rows_per_image > 0 && groups > 0)), "fie_gn_stats_target: bad argument");
+    ctx->gn_target = static_cast<float*>(partial);
+    ctx->gn_target_rows = rows_per_image;
+    ctx->gn_target_groups = groups;
+    return FIE_OK;
+}
+
 int fie_gemm_autotune(fie_ctx* ctx, int on) {
     FIE_REQUIRE(ctx != nullptr && on >= 0 && on <= 2, "fie_gemm_autotune: bad argument");
     ctx->autotune = on;
@@ -770,6 +778,19 @@ int fie_debug_gemm_stamps(fie_ctx* ctx, void* buf) {
 
 const char* fie_debug_last_gemm_kernel(fie_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }
 
+static int take_gn_target(const char* who, fie_ctx* ctx, GemmArgs& a) {
+    if (!ctx->gn_target) return FIE_OK;
+    a.gn_partial = ctx->gn_target;
+    a.gn_rows = (int)ctx->gn_target_rows;
+    a.gn_G = ctx->gn_target_groups;
+    ctx->gn_target = nullptr;                               // one shot
+    FIE_REQUIRE(a.act != FIE_ACT_GEGLU && a.N % a.gn_G == 0, "%s: GroupNorm statistics: N=%d not divisible into %d groups", who, a.N, a.gn_G);
+    a.gn_cg = a.N / a.gn_G;
+    FIE_REQUIRE(a.gn_cg == 4 || a.gn_cg == 8 || a.gn_cg == 16, "%s: GroupNorm statistics need 4, 8 or 16 channels per group (got %d)", who, a.gn_cg);
+    FIE_REQUIRE(a.gn_rows > 0 && a.gn_rows % 32 == 0 && a.M % a.gn_rows == 0, "%s: GroupNorm statistics: M=%d rows, %d per image (must be a multiple of 32)", who, a.M, a.gn_rows);
+    return FIE_OK;
+}
+
 static int gemm_impl(const char* who, fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2,
                      const void* Wpacked, int64_t ldw, const float* w_scale, void* C, int64_t ldc, int M, int N, int K, const void* bias,
                      const void* rowbias, int64_t ld_rowbias, int rows_per_batch, const void* residual, int64_t ldr, float scale, int act) {
@@ -790,6 +811,7 @@ static int gemm_impl(const char* who, fie_ctx* ctx, const void* A1, int64_t lda1
     a.a1_bytes = ((int64_t)(M - 1) * lda1 + K1) * 2;
     a.a2_bytes = A2 ? ((int64_t)(M - 1) * lda2 + (K - K1)) * 2 : 0;
     a.w_bytes = fie_roundup(N, 128) * ldw * (w_scale ? 1 : 2);
+    if (int rc = take_gn_target(who, ctx, a)) return rc;
     return launch<0>(ctx, a);
 }
 
@@ -836,6 +858,7 @@ static int conv_impl(const char* who, fie_ctx* ctx, const void* X, int B, int H,
     a.a1_bytes = (int64_t)B * H * W * Cin * 2;
     a.a2_bytes = 0;
     a.w_bytes = fie_roundup(Cout, 128) * ldw * (w_scale ? 1 : 2);
+    if (int rc = take_gn_target(who, ctx, a)) return rc;
     return launch<1>(ctx, a);
 }
 

@@ -117,6 +117,46 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GnArgsT<T> p, int B) {
     }
 }
 
+// The same reduction for the producer-written partials (one per 32-row granule: up to 32 768 per image at 1024^2): a whole
+// 256-thread block per (b, g), four independent accumulator pairs per thread so that the loads stay in flight.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_finalize_wide_kernel(GnArgsT<T> p, int B) {
+    __shared__ double red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x;
+    const int b = i / p.G, g = i - b * p.G;
+    const float2* src = reinterpret_cast<const float2*>(p.partial) + (int64_t)b * p.nchunks * p.G + g;
+    double a0 = 0.0, q0 = 0.0, a1 = 0.0, q1 = 0.0, a2 = 0.0, q2 = 0.0, a3 = 0.0, q3 = 0.0;
+    int c = tid;
+    for (; c + 768 < p.nchunks; c += 1024) {
+        const float2 v0 = src[(int64_t)c * p.G], v1 = src[(int64_t)(c + 256) * p.G], v2 = src[(int64_t)(c + 512) * p.G], v3 = src[(int64_t)(c + 768) * p.G];
+        a0 += (double)v0.x; q0 += (double)v0.y; a1 += (double)v1.x; q1 += (double)v1.y;
+        a2 += (double)v2.x; q2 += (double)v2.y; a3 += (double)v3.x; q3 += (double)v3.y;
+    }
+    for (; c < p.nchunks; c += 256) {
+        const float2 v = src[(int64_t)c * p.G];
+        a0 += (double)v.x; q0 += (double)v.y;
+    }
+    double a = (a0 + a1) + (a2 + a3), q = (q0 + q1) + (q2 + q3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        q += __shfl_xor(q, o);
+    }
+    if (lane == 0) { red[wave * 2] = a; red[wave * 2 + 1] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        a = (red[0] + red[2]) + (red[4] + red[6]);
+        q = (red[1] + red[3]) + (red[5] + red[7]);
+        const double n = (double)p.rows * p.cg;
+        const double mean = a / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        p.stats[i * 2] = (float)mean;
+        p.stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgsT<T> p) {
     const int tid = threadIdx.x;
@@ -403,7 +443,40 @@ int layernorm_t(const char* who, fie_ctx* ctx, const void* X, int64_t ldx, void*
 
 }  // namespace
 
+// GroupNorm whose first pass was done by the producer: `partial` holds (sum, sum of squares) per image, 32-row granule and group, written
+// by the epilogue of the GEMM / conv that produced X (fie_gn_stats_target); finalize over the granules, then apply: one read of the tensor
+// instead of two.
+template <typename T>
+int groupnorm_stats_t(const char* who, fie_ctx* ctx, const void* X, int C, void* Y, int B, int64_t rows_per_image, int groups, const void* gamma,
+                      const void* beta, float eps, int silu, const void* partial, void* workspace) {
+    FIE_REQUIRE(ctx && X && Y && gamma && beta && partial && workspace, "%s: NULL argument", who);
+    FIE_REQUIRE(C > 0 && C % 8 == 0 && B > 0 && groups > 0 && C % groups == 0 && rows_per_image > 0 && rows_per_image % 32 == 0,
+                "%s: bad shape C=%d G=%d rows=%lld", who, C, groups, (long long)rows_per_image);
+    GnArgsT<T> p = {};
+    p.X1 = (const T*)X; p.C1 = C; p.X2 = nullptr; p.C2 = 0; p.Y = (T*)Y;
+    p.C = C; p.G = groups; p.cg = C / groups; p.rows = rows_per_image;
+    p.gamma = (const T*)gamma; p.beta = (const T*)beta; p.eps = eps; p.silu = silu;
+    int csplit = 1;
+    FIE_REQUIRE(gn_plan(p, C, groups, rows_per_image, B, &csplit) == 0, "%s: cannot split C=%d (groups=%d) into aligned column blocks", who, C, groups);
+    const dim3 grid((unsigned)p.nchunks, (unsigned)B, (unsigned)csplit);
+    p.stats = (float*)workspace + (int64_t)B * GN_MAX_CHUNKS * groups * 2;
+    GnArgsT<T> f = p;                                       // finalize walks the producer's granules, apply its own row chunks
+    f.partial = const_cast<float*>((const float*)partial);
+    f.nchunks = (int)(rows_per_image / 32);
+    fie_launch(ctx, gn_finalize_wide_kernel<T>, dim3(B * groups), dim3(256), 0, f, B);
+    fie_launch(ctx, gn_apply_kernel<T>, grid, dim3(GN_THREADS), 0, p);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
 extern "C" {
+
+int64_t fie_gn_stats_bytes(int B, int64_t rows_per_image, int groups) { return (int64_t)B * (rows_per_image / 32) * groups * 2 * (int64_t)sizeof(float); }
+
+int fie_groupnorm_stats_nhwc_f16(fie_ctx* ctx, const void* X, int C, void* Y, int B, int64_t rows_per_image, int groups, const void* gamma,
+                                 const void* beta, float eps, int silu, const void* partial, void* workspace) {
+    return groupnorm_stats_t<half_t>("fie_groupnorm_stats_nhwc_f16", ctx, X, C, Y, B, rows_per_image, groups, gamma, beta, eps, silu, partial, workspace);
+}
 
 int64_t fie_groupnorm_workspace_bytes(int B, int64_t rows_per_image, int groups) {
     (void)rows_per_image;

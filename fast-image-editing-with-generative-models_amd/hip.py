@@ -76,6 +76,9 @@ SIGNATURES = {
     "fie_debug_tile_override": [_P, _c.c_char_p],
     "fie_debug_last_gemm_kernel": [_P],
     "fie_prefetch": [_P, _P, _L, _P, _I],
+    "fie_gn_stats_target": [_P, _P, _L, _I],
+    "fie_gn_stats_bytes": [_I, _L, _I],
+    "fie_groupnorm_stats_nhwc_f16": [_P, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _P],
     "fie_gemm_autotune": [_P, _I],
     "fie_gemm_autotune_report": [_P, ctypes.c_char_p, _I],
     "fie_debug_gemm_probe": [_P, _I],
@@ -105,7 +108,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.argtypes = args
-            fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes", "fie_time_embed_workspace_bytes") else _I
+            fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes", "fie_time_embed_workspace_bytes", "fie_gn_stats_bytes") else _I
         _lib.fie_last_error.restype = ctypes.c_char_p
         _lib.fie_last_error.argtypes = []
         _lib.fie_debug_last_gemm_kernel.restype = ctypes.c_char_p
@@ -190,6 +193,9 @@ class Context:
         self.h = h
         self._stream = None
         self._gn_ws = {}
+        self._gn_stats = {}
+        self._gn_gen = 0
+        self.gn_from_epilogue = os.environ.get("FIE_GN_FROM_EPILOGUE", "1") != "0"
         self._resize_tables = {}       # (in, out) -> (taps, bounds, ksize) of the LANCZOS resample, on the device
         self.ws_tag = 0
         self._keep = None              # list collecting the tensors allocated while a program is being recorded (Context.record)
@@ -313,8 +319,28 @@ class Context:
         return out
 
     # ------------------------------------------------------------------ ops
+    # ---- GroupNorm statistics from the producing GEMM / conv (include/fie.h: fie_gn_stats_target)
+    def _gn_stats_arm(self, rows_total, n, rows_per_image, groups):
+        """Arms the next launch to write GroupNorm partial sums of its [rows_total, n] output; returns the tag groupnorm() looks for on
+        the output tensor, or None when the shape is not eligible (channels per group not 4 / 8 / 16, rows not in 32-row granules)."""
+        if not self.gn_from_epilogue or self.f32 or not groups or n % groups or n // groups not in (4, 8, 16):
+            return None
+        if rows_per_image % 32 or rows_total % rows_per_image:
+            return None
+        b = rows_total // rows_per_image
+        need = lib().fie_gn_stats_bytes(b, rows_per_image, groups)
+        key = (self._stream, self.ws_tag)            # one buffer per stream and graph slot: a producer's sums are consumed before the next producer runs
+        buf = self._gn_stats.get(key)
+        if buf is None or buf.numel() < need:
+            buf = self._gn_stats[key] = torch.empty(need, device=self.device, dtype=torch.uint8)
+        if self._keep is not None:
+            self._keep.append(buf)
+        _chk(lib().fie_gn_stats_target(self.h, _p(buf), rows_per_image, groups))
+        self._gn_gen += 1
+        return (buf, groups, n, rows_per_image, b, self._gn_gen, key)
+
     def gemm(self, a, wp, n, out=None, a2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None, scale=1.0,
-             act=ACT_NONE, k=None):
+             act=ACT_NONE, k=None, gn_stats=None):
         """a: [M, K1] (last-dim contiguous, row stride free), optional a2: [M, K2]; wp packed weight; n logical N."""
         self.sync_stream()
         m, k1 = a.shape
@@ -337,14 +363,16 @@ class Context:
                                        rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
                                        residual.stride(0) if residual is not None else 0, float(scale), act))
             return out
+        tag = self._gn_stats_arm(m, n, gn_stats[0], gn_stats[1]) if gn_stats and act != ACT_GEGLU and out.stride(0) == n else None
         _chk(lib().fie_gemm_f16(self.h, _p(a), a.stride(0), k1, _p(a2), a2.stride(0) if a2 is not None else 0,
                                 _p(wp), wp.stride(0), _p(out), out.stride(0), m, n, ktot, _p(bias), _p(rowbias),
                                 rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
                                 residual.stride(0) if residual is not None else 0, float(scale), act))
+        out._gn_tag = tag
         return out
 
     def conv3x3(self, x, wp, cout, out=None, stride=1, pad_mode=0, upsample=False, bias=None, rowbias=None,
-                residual=None, scale=1.0, act=ACT_NONE, ldc=None):
+                residual=None, scale=1.0, act=ACT_NONE, ldc=None, gn_groups=None):
         """x: [B, H, W, Cin] f16 contiguous NHWC -> [B, OH, OW, ldc]."""
         self.sync_stream()
         b, h, w, cin = x.shape
@@ -362,10 +390,12 @@ class Context:
                                                residual.stride(2) if residual is not None else 0, float(scale), act))
             return out
         fn = lib().fie_conv3x3_nhwc_f32 if self.f32 else lib().fie_conv3x3_nhwc_f16
+        tag = self._gn_stats_arm(b * oh * ow, cout, oh * ow, gn_groups) if gn_groups and ldc == cout else None
         _chk(fn(self.h, _p(x), b, h, w, cin, int(upsample), stride, pad_mode, _p(wp),
                                         wp.stride(0), _p(out), out.stride(2), cout, _p(bias), _p(rowbias),
                                         rowbias.stride(0) if rowbias is not None else 0, _p(residual),
                                         residual.stride(2) if residual is not None else 0, float(scale), act))
+        out._gn_tag = tag
         return out
 
     def attention(self, q, k, v, heads, head_dim, tq, tk, batch, out=None, causal=False, scale=None):
@@ -405,6 +435,12 @@ class Context:
             ws = self._gn_ws[key] = torch.empty(need, device=self.device, dtype=torch.uint8)
         if self._keep is not None:
             self._keep.append(ws)
+        tag = getattr(x1, "_gn_tag", None)
+        if (tag is not None and x2 is None and tag[1:5] == (groups, c1, rows, b) and tag[5] == self._gn_gen and tag[6] == key):
+            # the producer's epilogue left this tensor's partial sums (and nothing has overwritten them): one read of x instead of two
+            _chk(lib().fie_groupnorm_stats_nhwc_f16(self.h, _p(x1), c1, _p(out), b, rows, groups, _p(gamma), _p(beta), float(eps), int(silu),
+                                                    _p(tag[0]), _p(ws)))
+            return out
         _chk((lib().fie_groupnorm_nhwc_f32 if self.f32 else lib().fie_groupnorm_nhwc_f16)(self.h, _p(x1), c1, _p(x2), c2, _p(out), b, rows, groups, _p(gamma),
                                           _p(beta), float(eps), int(silu), _p(ws)))
         return out

@@ -38,9 +38,9 @@ class Linear:
                 b = torch.stack([b[: self.n // 2], b[self.n // 2:]], 1).reshape(-1).contiguous()
         self.b = b
 
-    def __call__(self, ctx, a, a2=None, residual=None, act=None, scale=1.0, out=None, rowbias=None, rows_per_batch=0):
+    def __call__(self, ctx, a, a2=None, residual=None, act=None, scale=1.0, out=None, rowbias=None, rows_per_batch=0, gn_stats=None):
         return ctx.gemm(a, self.wp, self.n, a2=a2, bias=self.b, residual=residual, scale=scale, out=out,
-                        act=self.act if act is None else act, rowbias=rowbias, rows_per_batch=rows_per_batch)
+                        act=self.act if act is None else act, rowbias=rowbias, rows_per_batch=rows_per_batch, gn_stats=gn_stats)
 
 
 class Conv3:
@@ -58,9 +58,10 @@ class Conv3:
             b = bb
         self.b = b
 
-    def __call__(self, ctx, x, stride=1, pad_mode=0, upsample=False, rowbias=None, residual=None, act=hip.ACT_NONE):
+    def __call__(self, ctx, x, stride=1, pad_mode=0, upsample=False, rowbias=None, residual=None, act=hip.ACT_NONE, gn_groups=None):
+        """gn_groups: the output feeds a GroupNorm with that many groups -- have the epilogue leave its partial sums (hip.py: _gn_stats_arm)."""
         return ctx.conv3x3(x, self.wp, self.n, stride=stride, pad_mode=pad_mode, upsample=upsample, bias=self.b,
-                           rowbias=rowbias, residual=residual, act=act, ldc=max(self.ldc, self.n))
+                           rowbias=rowbias, residual=residual, act=act, ldc=max(self.ldc, self.n), gn_groups=gn_groups)
 
 
 class Norm:
@@ -80,14 +81,14 @@ class Resnet:
         b, h, w, _ = x.shape
         y = ctx.groupnorm(x, self.n1.g, self.n1.b, self.groups, self.eps, True, x2=skip)
         rb = temb_all[:, self.temb_slot[0]:self.temb_slot[1]] if self.temb_slot is not None else None
-        y = self.c1(ctx, y, rowbias=rb)
+        y = self.c1(ctx, y, rowbias=rb, gn_groups=self.groups)          # norm2's first pass rides on conv1's epilogue where the group width allows
         y = ctx.groupnorm(y, self.n2.g, self.n2.b, self.groups, self.eps, True)
         if self.sc is not None:
             res = self.sc(ctx, x.view(b * h * w, -1), a2=None if skip is None else skip.view(b * h * w, -1))
             res = res.view(b, h, w, -1)
         else:
             res = x
-        return self.c2(ctx, y, residual=res)
+        return self.c2(ctx, y, residual=res, gn_groups=self.groups)      # ... and the next block's norm on conv2's
 
 
 class TBlock:

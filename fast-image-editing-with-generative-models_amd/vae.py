@@ -24,7 +24,10 @@ class _MidAttn:
         y = ctx.groupnorm(x, self.norm.g, self.norm.b, self.groups, self.eps, False).view(b * h * w, c)
         qkv = self.qkv(ctx, y)
         a = ctx.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], 1, c, h * w, h * w, b)
-        return self.out(ctx, a, residual=x.view(b * h * w, c)).view(b, h, w, c)
+        o = self.out(ctx, a, residual=x.view(b * h * w, c), gn_stats=(h * w, self.groups))
+        y = o.view(b, h, w, c)
+        y._gn_tag = getattr(o, "_gn_tag", None)        # the view is a new tensor object: carry the producer's GroupNorm sums along
+        return y
 
 
 class VAE:
@@ -68,12 +71,12 @@ class VAE:
         """x: [1, H, W, 8] f16 in [-1, 1] (3 real channels) -> moments [H/8*W/8, 8] (mean | logvar)."""
         ctx, cfg = self.ctx, self.cfg
         g, eps = cfg["norm_num_groups"], cfg["norm_eps"]
-        x = self.e_in(ctx, x)
+        x = self.e_in(ctx, x, gn_groups=g)
         for rs, ds in self.e_down:
             for r in rs:
                 x = r(ctx, x)
             if ds is not None:
-                x = ds(ctx, x, stride=2, pad_mode=1)
+                x = ds(ctx, x, stride=2, pad_mode=1, gn_groups=g)
         r0, at, r1 = self.e_mid
         x = r1(ctx, at(ctx, r0(ctx, x)))
         x = ctx.groupnorm(x, self.e_norm.g, self.e_norm.b, g, eps, True)
@@ -87,13 +90,13 @@ class VAE:
         g, eps = cfg["norm_num_groups"], cfg["norm_eps"]
         b, h, w, c = z.shape
         x = self.post_quant(ctx, z.view(b * h * w, c)).view(b, h, w, 8)
-        x = self.d_in(ctx, x)
+        x = self.d_in(ctx, x, gn_groups=g)
         r0, at, r1 = self.d_mid
         x = r1(ctx, at(ctx, r0(ctx, x)))
         for rs, us in self.d_up:
             for r in rs:
                 x = r(ctx, x)
             if us is not None:
-                x = us(ctx, x, upsample=True)
+                x = us(ctx, x, upsample=True, gn_groups=g)
         x = ctx.groupnorm(x, self.d_norm.g, self.d_norm.b, g, eps, True)
         return self.d_out(ctx, x)

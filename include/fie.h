@@ -234,6 +234,18 @@ int fie_debug_tile_override(fie_ctx* ctx, const char* spec);       /* "mode,M,N,
  * Every tile accumulates K in the same order, so the choice does not change results.  on = 2 keeps using what is remembered but
  * tunes nothing new and frees the scratch (0.4 GB + one output); on = 0 returns to the built-in rule.  fie_gemm_autotune_report writes one "gemm|conv M= N= K= K1= geom= w8= -> code" line per remembered problem
  * into buf (NUL-terminated, truncated to cap) and returns the number of problems. */
+/* GroupNorm statistics from the producer's epilogue (upstream: the first of the three passes torch.nn.GroupNorm makes over the tensor,
+ * models/resnet.py norm1 / norm2, models/autoencoders/vae.py).  fie_gn_stats_target arms the NEXT fie_gemm_f16 / fie_conv3x3_nhwc_f16
+ * launch on this context (one shot): besides its output [M, N] it writes, per image (rows_per_image rows, a multiple of 32), per 32-row
+ * granule and per group, the sum and the sum of squares of the f16-ROUNDED outputs: partial[B][rows_per_image / 32][groups][2] floats
+ * (fie_gn_stats_bytes).  N / groups must be 4, 8 or 16 channels (the SDXL VAE's 128 / 256 / 512-channel maps with 32 groups); no GEGLU.
+ * Every slot has one writer: deterministic.  fie_groupnorm_stats_nhwc_f16 is fie_groupnorm_nhwc_f16 for such a tensor: it reduces the
+ * partials (fp64) and applies, reading X once instead of twice; workspace as for fie_groupnorm_nhwc_f16. */
+int fie_gn_stats_target(fie_ctx* ctx, void* partial, int64_t rows_per_image, int groups);
+int64_t fie_gn_stats_bytes(int B, int64_t rows_per_image, int groups);
+int fie_groupnorm_stats_nhwc_f16(fie_ctx* ctx, const void* X, int C, void* Y, int B, int64_t rows_per_image, int groups, const void* gamma,
+                                 const void* beta, float eps, int silu, const void* partial, void* workspace);
+
 /* Touches one dword of every 128-byte line of [ptr, ptr + bytes) with `blocks` small workgroups on `stream` (NULL: the context's): pulls a
  * weight matrix from HBM into the Infinity Cache ahead of the kernel that will stream it.  Reads only; no result. */
 int fie_prefetch(fie_ctx* ctx, const void* ptr, int64_t bytes, void* stream, int blocks);

@@ -467,6 +467,41 @@ def test_gemm_autotune_picks_by_measurement_and_keeps_results(fie):
     assert hip.last_gemm_kernel(fie) == rule_kernel
 
 
+@pytest.mark.parametrize("cout,code", [(128, 0), (256, 54), (512, 81), (128, 52), (256, 62), (128, 42), (512, 96), (256, 43)])
+def test_groupnorm_statistics_from_the_producing_conv(fie, cout, code):
+    """fie_gn_stats_target + fie_groupnorm_stats_nhwc_f16 (include/fie.h): the conv's epilogue leaves per-granule (sum, sum of squares) of its
+    f16-rounded output; GroupNorm from those equals the three-kernel GroupNorm of the same tensor (which re-reads it) and torch's;
+    4 / 8 / 16 channels per group (the VAE's 128 / 256 / 512-channel maps), two images, residual + bias in the epilogue, every tile
+    family, a ragged last row tile (M = 2 * 2304 = 4608 is not a multiple of 192 / 256)."""
+    from fie_amd import hip
+    b, h, w, cin, groups = 2, 48, 48, 64, 32
+    x = rnd(b, h, w, cin, seed=1).to(DEV)
+    wc = fie.pack_conv3x3(rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5).to(DEV))
+    bias, res = rnd(cout, seed=3).to(DEV), rnd(b, h, w, cout, seed=4).to(DEV)
+    gamma, beta = (1 + 0.1 * rnd(cout, seed=5)).to(DEV), (0.1 * rnd(cout, seed=6)).to(DEV)
+    fie.force_tile(code)
+    try:
+        y = fie.conv3x3(x, wc, cout, bias=bias, residual=res, gn_groups=groups)
+    finally:
+        fie.force_tile(0)
+    assert y._gn_tag is not None
+    fast = fie.groupnorm(y, gamma, beta, groups, 1e-6, True)
+    slow = fie.groupnorm(y.clone(), gamma, beta, groups, 1e-6, True)           # the clone carries no tag: gn_partial / finalize / apply
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(y.float().permute(0, 3, 1, 2), groups, gamma.float(), beta.float(), 1e-6)).permute(0, 2, 3, 1)
+    assert rel_err(fast, slow.float()) < 1e-3 and rel_err(fast, ref) < 4e-3
+    # a producer in between invalidates the tag (its sums overwrote the buffer): the plain path runs and still agrees
+    fie.conv3x3(x, wc, cout, gn_groups=groups)
+    again = fie.groupnorm(y, gamma, beta, groups, 1e-6, True)
+    assert torch.equal(again, slow)
+    # GEMM producer (the VAE mid-block attention's output projection, + residual)
+    a2d, wl = rnd(b * h * w, 64, seed=7).to(DEV), fie.pack_linear(rnd(cout, 64, seed=8, scale=0.125).to(DEV))
+    o = fie.gemm(a2d, wl, cout, bias=bias, residual=res.view(b * h * w, cout), gn_stats=(h * w, groups))
+    o4 = o.view(b, h, w, cout)
+    o4._gn_tag = o._gn_tag
+    assert o._gn_tag is not None
+    assert rel_err(fie.groupnorm(o4, gamma, beta, groups, 1e-6, False), fie.groupnorm(o4.clone(), gamma, beta, groups, 1e-6, False).float()) < 1e-3
+
+
 def test_time_embed_fused(fie):
     """K7 fused kernel against the unfused route it replaces (embeddings.py): sinusoid -> Linear -> SiLU -> Linear, + the
     text-time embedding, SiLU; SDXL dims (320 -> 1280 -> 1280) and the tiny stack's (64 -> 256), batch 1 / 2 / 4, t = 499 KAT
