@@ -418,18 +418,20 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
 
 // ---- tile codes (also the values fie_debug_force_tile / fie_debug_tile_override take)
 //   1 / 2 / 3      gemm_kernel   128x128 / 128x64 / 64x64 (any shape)
-//   41 / 42 / 43   gemm3_kernel  128x128 / 128x64 / 64x64, 3 stages, 4 waves
+//   42 / 43        gemm3_kernel  128x64 / 64x64, 3 stages, 4 waves (two / three blocks per CU)
+//   44 / 46        the same tiles with 2 stages (three / five blocks per CU)
+//   52 / 54        gemm3_kernel  128x128 / 192x128, 2 stages, 8 waves: two blocks per CU
 //   51             gemm3_kernel  128x128, 3 stages, 8 waves
 //   61 / 62        gemm3_kernel  256x256 x 2 stages / 256x128 x 3 stages, 8 waves
 //   + 1000 / + 2000  force the tile order (n-tiles / m-tiles fastest); plain codes estimate it
-//   91 / 92 / 93 / 95 / 96   gemm3_kernel 41 / 42 / 43 / 51 / 62 with fragment reads one half K-step ahead of the MFMAs
+//   95 / 96        gemm3_kernel 51 / 62 with fragment reads one half K-step ahead of the MFMAs (the 4-wave and 2-stage tiles gain nothing from it)
 //   97 / 98 / 94   62 / 96 / 42 with in-kernel cycle stamps (fie_debug_gemm_stamps; slower, for tools/kstep_stamps.py only)
 //   81 / 82        gemm8_kernel  256x256 phased (82: second DMA piece of each phase inside the MFMA cluster, A/B: slower)
 struct TileDim { int code, bm, bn; };
-constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {41, 128, 128}, {42, 128, 64}, {43, 64, 64},
+constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {42, 128, 64}, {43, 64, 64},
                               {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256},
-                              {91, 128, 128}, {92, 128, 64}, {93, 64, 64}, {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
-                              {52, 128, 128}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}, {45, 128, 128}, {53, 128, 128}};
+                              {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
+                              {52, 128, 128}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}};
 
 // Heuristic tile code for a shape (the default; the autotuner below and the debug hooks can replace it).
 template <int MODE>
@@ -446,14 +448,14 @@ int heuristic_code(const fie_ctx* ctx, const GemmArgs& a, bool dma_ok) {
     } else if (MODE == 1) {
         if ((b256 >= cus && (a.N % 256 == 0 || (a.N % 128 != 0 && a.K >= 5760))) ||        // 256x256 phased: VAE 256/512-ch maps, 128x128-latent convs into 320 ch
             (a.N % 256 == 0 && a.K >= 8192 && 2 * b256 >= cus)) code = 81;                  // ... and the long-K upsampling convs of the 32x32 level
-        else if (a.N % 128 == 0 && b62 >= 150) code = 62;
+        else if (a.N % 128 == 0 && b62 >= 150) code = 96;
         else if (a.N % 128 == 0 && a.K >= 5760 && b51 >= 100) code = 51;                     // 32x32-latent convs: 160 x (128x128), 8 waves
         else if (2 * b42 < 3 * cus) code = 43;                                               // stride-2 convs and other small grids
         else code = 42;
     } else if (a.N % 256 == 0 && a.K >= 4096 && b256 >= cus) {
         code = 81;
     } else if (a.N % 128 == 0 && b62 >= 150 && (a.N >= 1536 || a.K >= 2048 || a.M >= 16384)) {
-        code = 62;
+        code = 96;
     } else if (a.N >= 2048 && a.K >= 1024 && b51 >= cus) {
         code = 51;
     } else if (a.K <= 640 && a.N <= 640) {
@@ -491,7 +493,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok) {
     }
     if (a.w_scale) {                 // fp8 weights: the three W8 ring tiles (gemm_w8.hip)
         FIE_REQUIRE(dma_ok, "fp8 weights: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)");
-        code = (code == 81 || code == 82 || code == 61 || code == 62) ? 62 : (code == 43 || code == 3) ? 43 : 42;
+        code = (code == 43 || code == 46 || code == 3) ? 43 : (code == 42 || code == 44 || code == 2) ? 42 : 62;
         for (const TileDim& d : kTiles)
             if (d.code == code) t = &d;
     }
@@ -512,7 +514,6 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok) {
         case 1: fie_launch(ctx, (gemm_kernel<128, 128, MODE>), grid, block, 0, a); break;
         case 2: fie_launch(ctx, (gemm_kernel<128, 64, MODE>), grid, block, 0, a); break;
         case 3: fie_launch(ctx, (gemm_kernel<64, 64, MODE>), grid, block, 0, a); break;
-        case 41: launch_ring<128, 128, 3, M3, 4>(ctx, a, grid); break;
         case 42: launch_ring<128, 64, 3, M3, 4>(ctx, a, grid); break;
         case 43: launch_ring<64, 64, 3, M3, 4>(ctx, a, grid); break;
         case 51: launch_ring<128, 128, 3, M3, 8>(ctx, a, grid); break;
@@ -522,11 +523,6 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok) {
         case 54: launch_ring<192, 128, 2, M3, 8>(ctx, a, grid); break;
         case 46: launch_ring<64, 64, 2, M3, 4>(ctx, a, grid); break;
         case 44: launch_ring<128, 64, 2, M3, 4>(ctx, a, grid); break;
-        case 45: launch_ring<128, 128, 2, M3, 4>(ctx, a, grid); break;
-        case 53: launch_ring<128, 128, 2, M3, 8, true>(ctx, a, grid); break;
-        case 91: launch_ring<128, 128, 3, M3, 4, true>(ctx, a, grid); break;
-        case 92: launch_ring<128, 64, 3, M3, 4, true>(ctx, a, grid); break;
-        case 93: launch_ring<64, 64, 3, M3, 4, true>(ctx, a, grid); break;
         case 95: launch_ring<128, 128, 3, M3, 8, true>(ctx, a, grid); break;
         case 96: launch_ring<256, 128, 3, M3, 8, true>(ctx, a, grid); break;
         case 97: launch_ring<256, 128, 3, M3, 8, false, true>(ctx, a, grid); break;
@@ -671,8 +667,7 @@ __global__ void pack_conv_kernel(const half_t* src, int Cout, int Cin, int cin_p
 
 template <int MODE>
 hipError_t ring_attrs() {
-    hipError_t e = ring_attr<128, 128, 3, MODE, 4>();
-    if (e == hipSuccess) e = ring_attr<128, 64, 3, MODE, 4>();
+    hipError_t e = ring_attr<128, 64, 3, MODE, 4>();
     if (e == hipSuccess) e = ring_attr<64, 64, 3, MODE, 4>();
     if (e == hipSuccess) e = ring_attr<128, 128, 3, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<256, 256, 2, MODE, 8>();
@@ -681,11 +676,6 @@ hipError_t ring_attrs() {
     if (e == hipSuccess) e = ring_attr<192, 128, 2, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<64, 64, 2, MODE, 4>();
     if (e == hipSuccess) e = ring_attr<128, 64, 2, MODE, 4>();
-    if (e == hipSuccess) e = ring_attr<128, 128, 2, MODE, 4>();
-    if (e == hipSuccess) e = ring_attr<128, 128, 2, MODE, 8, true>();
-    if (e == hipSuccess) e = ring_attr<128, 128, 3, MODE, 4, true>();
-    if (e == hipSuccess) e = ring_attr<128, 64, 3, MODE, 4, true>();
-    if (e == hipSuccess) e = ring_attr<64, 64, 3, MODE, 4, true>();
     if (e == hipSuccess) e = ring_attr<128, 128, 3, MODE, 8, true>();
     if (e == hipSuccess) e = ring_attr<256, 128, 3, MODE, 8, true>();
     if (e == hipSuccess) e = ring_attr<256, 128, 3, MODE, 8, false, true>();
