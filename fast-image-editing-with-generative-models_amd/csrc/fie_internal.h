@@ -54,6 +54,7 @@ struct fie_ctx {
     float* gn_target = nullptr;              // fie_gn_stats_target: consumed by the next GEMM / conv launch
     int64_t gn_target_rows = 0;
     int gn_target_groups = 0;
+    int gn_onepass = 1;                      // fie_debug_gn_onepass: 0 = always the three-kernel GroupNorm
     int autotune = 0;                        // fie_gemm_autotune: time the eligible tiles at a shape's first eager launch
     std::map<fie_tune_key, int> tuned;
     void* tune_buf = nullptr;                // scratch output of the timing launches

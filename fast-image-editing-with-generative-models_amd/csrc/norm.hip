@@ -197,7 +197,6 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgsT<T> p) {
 // partial / finalize / apply (three launches, two reads; ~25 us -> ~8 us on a 2 x 1024 x 1280 map, which is pure launch latency).
 // A thread keeps one fixed channel piece (the block uses (1024 / npv) * npv threads), so gamma / beta live in registers.
 constexpr int GN1_THREADS = 1024;
-int g_gn_onepass = 1;      // tuning hook (fie_debug_gn_onepass): 0 = always the three-kernel path
 
 template <int ND>
 struct alignas(ND * 4) GnRaw { uint32_t d[ND]; };       // one vector of V channels as raw dwords (ND = V * sizeof(T) / 4)
@@ -416,7 +415,7 @@ int groupnorm_t(const char* who, fie_ctx* ctx, const void* X1, int C1, const voi
     p.gamma = (const T*)gamma; p.beta = (const T*)beta; p.eps = eps; p.silu = silu;
     int csplit = 1;
     FIE_REQUIRE(gn_plan(p, C, groups, rows_per_image, B, &csplit) == 0, "%s: cannot split C=%d (groups=%d) into aligned column blocks", who, C, groups);
-    if (g_gn_onepass && gn_onepass(ctx, p, B)) {
+    if (ctx->gn_onepass && gn_onepass(ctx, p, B)) {
         FIE_LAUNCH_CHECK();
         return FIE_OK;
     }
@@ -507,7 +506,8 @@ int fie_layernorm_f32(fie_ctx* ctx, const void* X, int64_t ldx, void* Y, int64_t
 
 }  // extern "C"
 
-extern "C" int fie_debug_gn_onepass(int enable) {
-    g_gn_onepass = enable;
+extern "C" int fie_debug_gn_onepass(fie_ctx* ctx, int enable) {
+    FIE_REQUIRE(ctx != nullptr, "fie_debug_gn_onepass: NULL ctx");
+    ctx->gn_onepass = enable;
     return FIE_OK;
 }

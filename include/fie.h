@@ -255,7 +255,7 @@ int fie_debug_gemm_probe(fie_ctx* ctx, int mode);                  /* TIMING-ONL
 int fie_debug_gemm_stamps(fie_ctx* ctx, void* buf);                  /* device buffer for the stamped ring kernels (tile codes 97 / 98): per tile and wave 8 uint32 cycle sums -- [0] drain + barrier, [1]/[4] DMA issue, [2]/[5] fragment reads, [3]/[6] MFMA issue (code 98: [0] = whole K-steps); NULL detaches */
 const char* fie_debug_last_gemm_kernel(fie_ctx* ctx);              /* kernel / tile of the last fie_gemm_f16 / fie_conv3x3_nhwc_f16 launch */
 int fie_debug_attn_variant(int variant);   /* 0 = default kernel, 1 = first-generation kernel (A/B benchmarking) */
-int fie_debug_gn_onepass(int enable);      /* 1 = default (single-pass GroupNorm on small maps), 0 = always partial/finalize/apply */
+int fie_debug_gn_onepass(fie_ctx* ctx, int enable);      /* per context; 1 = default (single-pass GroupNorm on small maps), 0 = always partial/finalize/apply */
 
 /* ---- K11 Canny on the host (integer exact).  Replaces cv2.cvtColor(RGB2GRAY) + cv2.Canny at
  * src/pipeline.py:200,205 and the 3-channel stack at :208.  rgb, edges_rgb: host u8 [H, W, 3]. */

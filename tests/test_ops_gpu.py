@@ -174,10 +174,10 @@ def test_groupnorm_single_pass_matches_three_kernel_path(fie, b, rows, c1, c2):
     gamma, beta = rnd(c1 + c2, seed=3).to(DEV), rnd(c1 + c2, seed=4).to(DEV)
     one = fie.groupnorm(x1, gamma, beta, 32, 1e-5, True, x2=x2)
     try:
-        hip.lib().fie_debug_gn_onepass(0)
+        hip.lib().fie_debug_gn_onepass(fie.h, 0)
         three = fie.groupnorm(x1, gamma, beta, 32, 1e-5, True, x2=x2)
     finally:
-        hip.lib().fie_debug_gn_onepass(1)
+        hip.lib().fie_debug_gn_onepass(fie.h, 1)
     assert rel_err(one, three.float()) < 1e-3
 
 

@@ -109,12 +109,12 @@ def run_norm():
         nv = -(-rows // (1024 // (cg // v))) if v else 0
         single = (v == 8 and nv <= 10) or (v == 4 and nv <= 20)          # csrc/norm.hip gn_onepass()
         for onepass in ((1, 0) if single else (0,)):
-            hip.lib().fie_debug_gn_onepass(onepass)
+            hip.lib().fie_debug_gn_onepass(ctx.h, onepass)
             dt = timeit(lambda: ctx.groupnorm(x, g, bt, 32, 1e-5, True, out=out))
             passes = 2 if onepass else 3
             print(f"groupnorm+SiLU {note:24s} B={b} rows={rows:8d} C={c:5d} {'single-pass' if onepass else '3-kernel   '}: {dt * 1e6:7.1f} us "
                   f"{passes * x.numel() * 2 / dt / 1e9:7.0f} GB/s ({passes} passes over the tensor)", flush=True)
-        hip.lib().fie_debug_gn_onepass(1)
+        hip.lib().fie_debug_gn_onepass(ctx.h, 1)
     for rows, c in [(2048, 1280), (8192, 640), (154, 1280)]:
         x = torch.randn(rows, c, device=DEV, dtype=torch.float16)
         g, bt = torch.randn(c, device=DEV, dtype=torch.float16), torch.randn(c, device=DEV, dtype=torch.float16)
