@@ -493,7 +493,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok) {
     }
     if (a.w_scale) {                 // fp8 weights: the three W8 ring tiles (gemm_w8.hip)
         FIE_REQUIRE(dma_ok, "fp8 weights: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)");
-        code = (code == 43 || code == 46 || code == 3) ? 43 : (code == 42 || code == 44 || code == 2) ? 42 : 62;
+        code = (code == 43 || code == 46 || code == 3) ? 43 : (code == 42 || code == 44 || code == 2) ? 42 : (code == 52 || code == 54) ? code : 62;
         for (const TileDim& d : kTiles)
             if (d.code == code) t = &d;
     }
@@ -550,7 +550,7 @@ constexpr size_t kFlushBytes = 384u << 20;
 template <int MODE>
 int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81};
-    static const int kW8[] = {43, 42, 62};
+    static const int kW8[] = {43, 42, 62, 52, 54};
     const size_t bytes = (size_t)a.M * (size_t)a.ldc * sizeof(half_t);
     if (bytes > ctx->tune_bytes) {
         if (ctx->tune_buf) (void)hipFree(ctx->tune_buf);
@@ -585,7 +585,7 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     int best = guess;
     float t_best = t_guess * 0.97f;                          // a challenger has to win by 3 %
     const int* cand = a.w_scale ? kW8 : kRing;
-    const int ncand = a.w_scale ? 3 : 9;
+    const int ncand = a.w_scale ? 5 : 9;
     for (int i = 0; i < ncand; ++i) {
         const int c = cand[i];
         if (c == guess) continue;

@@ -216,6 +216,10 @@ int fie_gemm_w8_init(void) {
     set(reinterpret_cast<const void*>(&gemm3w8_kernel<128, 64, 3, 2, 4>), w8_lds<128, 64, 3>());
     set(reinterpret_cast<const void*>(&gemm3w8_kernel<64, 64, 3, 0, 4>), w8_lds<64, 64, 3>());
     set(reinterpret_cast<const void*>(&gemm3w8_kernel<64, 64, 3, 2, 4>), w8_lds<64, 64, 3>());
+    set(reinterpret_cast<const void*>(&gemm3w8_kernel<128, 128, 2, 0, 8>), w8_lds<128, 128, 2>());
+    set(reinterpret_cast<const void*>(&gemm3w8_kernel<128, 128, 2, 2, 8>), w8_lds<128, 128, 2>());
+    set(reinterpret_cast<const void*>(&gemm3w8_kernel<192, 128, 2, 0, 8>), w8_lds<192, 128, 2>());
+    set(reinterpret_cast<const void*>(&gemm3w8_kernel<192, 128, 2, 2, 8>), w8_lds<192, 128, 2>());
     if (e != hipSuccess) {
         fie_set_error("gemm_w8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return FIE_EHIP;
@@ -223,17 +227,19 @@ int fie_gemm_w8_init(void) {
     return FIE_OK;
 }
 
-template <int BM, int BN, int NW>
+template <int BM, int BN, int NW, int ST = 3>
 static void launch_w8(fie_ctx* ctx, const GemmArgs& a, int conv, dim3 grid) {
-    constexpr int lds = w8_lds<BM, BN, 3>();
-    if (conv) fie_launch(ctx, (gemm3w8_kernel<BM, BN, 3, 2, NW>), grid, dim3(NW * 64), lds, a);
-    else fie_launch(ctx, (gemm3w8_kernel<BM, BN, 3, 0, NW>), grid, dim3(NW * 64), lds, a);
+    constexpr int lds = w8_lds<BM, BN, ST>();
+    if (conv) fie_launch(ctx, (gemm3w8_kernel<BM, BN, ST, 2, NW>), grid, dim3(NW * 64), lds, a);
+    else fie_launch(ctx, (gemm3w8_kernel<BM, BN, ST, 0, NW>), grid, dim3(NW * 64), lds, a);
 }
 
-// code: 62 (256x128, 8 waves), 42 (128x64), 43 (64x64)
+// code: 62 (256x128 x 3 stages, 8 waves), 42 (128x64), 43 (64x64), 52 / 54 (128x128 / 192x128 x 2 stages, 8 waves: two and more blocks per CU)
 int fie_launch_gemm_w8(fie_ctx* ctx, const GemmArgs& a, int conv, int code) {
     const dim3 grid((unsigned)(a.nbm * a.nbn));
     if (code == 62) launch_w8<256, 128, 8>(ctx, a, conv, grid);
+    else if (code == 54) launch_w8<192, 128, 8, 2>(ctx, a, conv, grid);
+    else if (code == 52) launch_w8<128, 128, 8, 2>(ctx, a, conv, grid);
     else if (code == 42) launch_w8<128, 64, 4>(ctx, a, conv, grid);
     else launch_w8<64, 64, 4>(ctx, a, conv, grid);
     FIE_LAUNCH_CHECK();

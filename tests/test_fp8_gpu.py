@@ -56,7 +56,7 @@ def test_pack_rows_f8_scales_and_bytes(fie8):
     assert torch.equal(wg[0:200:2], ref[:100]) and torch.equal(wg[1:200:2], ref[100:200])
 
 
-@pytest.mark.parametrize("code", [0, 42, 43, 62])
+@pytest.mark.parametrize("code", [0, 42, 43, 62, 52, 54])
 def test_gemm_w8_matches_quantised_reference(fie8, code):
     from fie_amd import hip
     fie8.force_tile(code)
@@ -85,7 +85,7 @@ def test_gemm_w8_matches_quantised_reference(fie8, code):
     assert rel_err(out, wp.dequant().cpu()[:256, :256].T) < 1e-3
 
 
-@pytest.mark.parametrize("code", [0, 42, 43, 62])
+@pytest.mark.parametrize("code", [0, 42, 43, 62, 52, 54])
 def test_conv_w8_matches_quantised_reference(fie8, code):
     from fie_amd import hip
     fie8.force_tile(code)
