@@ -143,6 +143,25 @@ def time_unet_forward(pipe, job, iters=3):
     return best
 
 
+def pmc_traffic(kernel, m, n, k, path=None):
+    """(MB per launch, source CSVs) from the PMC record of `kernel` on shape (m, n, k), or (None, None): the record file holds one
+    record per tile code the autotuner may pick (tools/collect_dominant_pmc.sh); the run's kernel name carries the code it used."""
+    try:
+        with open(path or os.path.join(ROOT, "profiles", "dominant_kernel_pmc.json")) as f:
+            rec = json.load(f)
+        if "fp8" in kernel:
+            raise KeyError("the PMC records are for the f16-weight kernels")
+        if "records" in rec:
+            code = kernel.split("tile code ")[-1].split(")")[0]
+            rec = dict(rec["records"][code], shape=rec["shape"])
+        if [rec["shape"]["M"], rec["shape"]["N"], rec["shape"]["K"]] != [m, n, k]:
+            return None, None
+        # gfx950: FETCH_SIZE counts a wide coalesced read at half its bytes (MI355X_MICROARCH.md, HBM) -> 2 x FETCH + WRITE
+        return round((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024 / 1e6, 1), rec.get("source")
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def time_dominant_kernel(pipe, nb, iters=20):
     """The single kernel with the largest share of device time (profiles/r02_per_edit_kernels.md): the GEMM on the UNet's
     32x32-latent FF1 projection (M = nb*1024 tokens, N = 10240, K = 1280, bias + GEGLU epilogue).  Average launch duration by
@@ -172,21 +191,7 @@ def time_dominant_kernel(pipe, nb, iters=20):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     tf = 2.0 * m * n * k / (us * 1e-6) / 1e12
-    traffic_mb, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "dominant_kernel_pmc.json")) as f:
-            rec = json.load(f)
-        if "fp8" in kernel:
-            raise KeyError("the PMC records are for the f16-weight kernels")
-        if "records" in rec:                                  # one record per tile code the autotuner may pick for this shape
-            code = kernel.split("tile code ")[-1].rstrip(")")
-            rec = dict(rec["records"][code], shape=rec["shape"])
-        if [rec["shape"]["M"], rec["shape"]["N"], rec["shape"]["K"]] == [m, n, k]:
-            # gfx950: FETCH_SIZE counts a wide coalesced read at half its bytes (MI355X_MICROARCH.md, HBM) -> 2 x FETCH + WRITE
-            traffic_mb = round((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024 / 1e6, 1)
-            traffic_src = rec.get("source")
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic_mb, traffic_src = pmc_traffic(kernel, m, n, k)
     return {"kernel": f"{kernel} (FF1 GEGLU projection, 32x32 latents)", "shape": {"M": m, "N": n, "K": k},
             "avg_us": round(us, 2), "launches": iters, "achieved": round(tf, 1), "frac": round(tf / PEAK_F16_DENSE_TFLOPS, 4),
             "algorithmic_gflop_per_launch": round(2.0 * m * n * k / 1e9, 2),

@@ -100,3 +100,22 @@ def test_in_flight_workers_cover_every_entry_once(dataset, tmp_path):
     assert ed.in_flight == 2 and ed.slots == {0, 1}
     assert (r["processed"], r["failed"]) == (7, 3) and sorted(ed.calls) == sorted(e["editing_prompt"] for _, _, e in entries[:7])
     assert [row["index"] for row in r["rows"]] == list(range(7))
+
+
+def test_bench_reads_the_pmc_record_of_the_tile_it_ran(tmp_path):
+    """bench.py roofline.traffic (contract: PMC bytes of the dominant kernel, or null): the committed record holds one entry per tile code the
+    autotuner may pick for the FF1 shape; the kernel name of the run selects it; an unknown tile, another shape, the fp8-weight kernels or
+    a missing file give null instead of some other kernel's bytes."""
+    import json
+
+    import bench
+    name = "gemm3_kernel<192x128> (gemm, tile code 54) (FF1 GEGLU projection, 32x32 latents)"
+    mb, src = bench.pmc_traffic(name, 2048, 10240, 1280)
+    assert mb is not None and 50 < mb < 400 and src and all("counter_collection" in s for s in src)
+    assert bench.pmc_traffic(name.replace("code 54", "code 43"), 2048, 10240, 1280) == (None, None)
+    assert bench.pmc_traffic(name, 4096, 10240, 1280) == (None, None)
+    assert bench.pmc_traffic("gemm3w8_kernel<128x128> (gemm, fp8 weights, tile code 54)", 2048, 10240, 1280) == (None, None)
+    assert bench.pmc_traffic(name, 2048, 10240, 1280, path=str(tmp_path / "absent.json")) == (None, None)
+    single = tmp_path / "single.json"                        # the single-record form of round 1
+    single.write_text(json.dumps({"shape": {"M": 8, "N": 8, "K": 8}, "fetch_size_kib": 1000.0, "write_size_kib": 48.0, "source": ["x.csv"]}))
+    assert bench.pmc_traffic("any kernel (tile code 1)", 8, 8, 8, path=str(single)) == (round((2 * 1000.0 + 48.0) * 1024 / 1e6, 1), ["x.csv"])
