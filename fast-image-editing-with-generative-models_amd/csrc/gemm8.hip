@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
         constexpr int S = decltype(setc)::value;
         if (MODE != 2 || kt >= nk) return;
         if (cs[S] == 0) {
-            const int ky = (ftap[S] * 11) >> 5, kx = ftap[S] - 3 * ky;
+            const int ky = p.taps2 ? ftap[S] >> 1 : (ftap[S] * 11) >> 5, kx = p.taps2 ? ftap[S] & 1 : ftap[S] - 3 * ky;
             const int hlim = p.H << p.ups, wlim = p.W << p.ups;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {

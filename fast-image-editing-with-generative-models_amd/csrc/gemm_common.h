@@ -29,6 +29,10 @@ struct GemmArgs {
     float scale; int act;
     int nbm, nbn;
     int64_t a1_bytes, a2_bytes, w_bytes;   // operand extents for the v3 buffer descriptors
+    // 2x-upsampling conv as four 2x2 convs (fie_conv_up2x_nhwc_f16): taps2 = the conv view has 2x2 taps (K = 4 * Cin) with pt / pl = 1 - parity;
+    // oscat = output row m = (b, oh, ow) of the OH x OW view is stored at pixel (2 oh + opy, 2 ow + opx) of the [B, 2 OH, 2 OW] output
+    int taps2, oscat, opy, opx;
+    int gn_nch, gn_chunk0;                  // GroupNorm partials: granules per image in the buffer (0: gn_rows / 32) and this launch's first granule
     float* gn_partial; int gn_rows, gn_G, gn_cg;   // GroupNorm statistics of the OUTPUT (fie_gn_stats_target): per image and 32-row granule [b][gn_rows / 32][gn_G][2] = (sum, sum of squares) of the f16-rounded values, gn_cg = N / gn_G in {4, 8, 16} channels per group; NULL: none
     const float* w_scale;                   // fp8 weights (gemm_w8.hip): per-output-channel dequantisation scale [N], applied to the accumulator first; Wt then points at e4m3 bytes and ldw counts bytes
     unsigned* stamps;                       // tile codes 97 / 98: [tile][wave][8] cycle sums of the K-loop segments (fie_debug_gemm_stamps), else NULL
@@ -70,6 +74,13 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
     constexpr unsigned kRowOut = 0x80000000u, kColOut = 0xC0000000u;    // any sum with a span <= 1 GiB stays out of range
     auto coff = [&](int i, bool half) { const int n = ncol + i * 16; return n < p.N ? (unsigned)n << (half ? 0 : 1) : kColOut; };   // bytes; half (GEGLU): output column n / 2
     auto roff = [&](int j, int64_t ld) { const int m = mrow + j * 16; return m < p.M ? (unsigned)m * (unsigned)ld * 2u : kRowOut; };
+    auto coff_row = [&](int j) {                            // byte offset of output row j in C: scattered for the parity convs of a 2x upsampling
+        const int m = mrow + j * 16;
+        if (m >= p.M) return kRowOut;
+        if (!p.oscat) return (unsigned)m * (unsigned)p.ldc * 2u;
+        const int hw = p.OH * p.OW, b = m / hw, rem = m - b * hw, oh = rem / p.OW, ow = rem - oh * p.OW;
+        return (unsigned)((b * 2 * p.OH + 2 * oh + p.opy) * (2 * p.OW) + 2 * ow + p.opx) * (unsigned)p.ldc * 2u;
+    };
     auto rsrc = [&](const void* ptr, int64_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000); };
     auto as_h4 = [](u32x2 v) { f16x4 h; __builtin_memcpy(&h, &v, 8); return h; };
 
@@ -152,7 +163,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
         // two fragments of a 32-row granule, columns over 1 / 2 / 4 fq lanes.  One lane per (granule, group) stores: every slot has
         // exactly one writer, so the sums are deterministic.  WM % 32 == 0 for every tile.
         static_assert(FM % 2 == 0, "row granules are two fragments");
-        const int nch = p.gn_rows >> 5;
+        const int nch = p.gn_nch ? p.gn_nch : p.gn_rows >> 5;
 #pragma unroll
         for (int jj = 0; jj < FM / 2; ++jj) {
             float sum[FN], sq[FN];
@@ -171,7 +182,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
                     }
             }
             const int mg = m0 + wm * WM + jj * 32;          // first row of the granule (wave-uniform)
-            const int b = mg / p.gn_rows, chunk = (mg - b * p.gn_rows) >> 5;
+            const int b = mg / p.gn_rows, chunk = p.gn_chunk0 + ((mg - b * p.gn_rows) >> 5);
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 // 16 rows: four DPP adds (xor 1, xor 2, mirror in 8, mirror in 16) leave the row-of-16 total in every lane, VALU only;
@@ -197,11 +208,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
         }
     }
     // ---- stores: lane holds C[m = .. + fr][n = .. + fq*4 + (0..3)]
-    const __amdgpu_buffer_rsrc_t rs_c = rsrc(p.C, BUF ? ((int64_t)(p.M - 1) * p.ldc + (geglu ? p.N >> 1 : p.N)) * 2 : 0);
+    const __amdgpu_buffer_rsrc_t rs_c = rsrc(p.C, BUF ? ((int64_t)(p.oscat ? 4 * (int64_t)p.M : p.M) - 1) * p.ldc * 2 + (geglu ? p.N >> 1 : p.N) * 2 : 0);
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
         const int m = mrow + j * 16;
-        const unsigned ro = roff(j, p.ldc);
+        const unsigned ro = coff_row(j);
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
             const int n = ncol + i * 16;

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         half_t* sa = smem + stage * STAGE;
         if (MODE == 2) {
             if (cs == 0) {
-                const int ky = (ftap * 11) >> 5, kx = ftap - 3 * ky;
+                const int ky = p.taps2 ? ftap >> 1 : (ftap * 11) >> 5, kx = p.taps2 ? ftap & 1 : ftap - 3 * ky;
                 const int hlim = p.H << p.ups, wlim = p.W << p.ups;
 #pragma unroll
                 for (int i = 0; i < RA; ++i) {
@@ -551,7 +551,7 @@ template <int MODE>
 int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81};
     static const int kW8[] = {43, 42, 62, 52, 54};
-    const size_t bytes = (size_t)a.M * (size_t)a.ldc * sizeof(half_t);
+    const size_t bytes = (size_t)a.M * (a.oscat ? 4 : 1) * (size_t)a.ldc * sizeof(half_t);     // a parity conv scatters its M rows over 4 M output rows
     if (bytes > ctx->tune_bytes) {
         if (ctx->tune_buf) (void)hipFree(ctx->tune_buf);
         ctx->tune_buf = nullptr;
@@ -603,7 +603,7 @@ template <int MODE>
 int launch(fie_ctx* ctx, GemmArgs& a) {
     // LDS-DMA kernels (codes >= 40): 32-bit buffer offsets (operands < 2 GiB) and K-steps that never straddle a 3x3 tap / the A1|A2 seam
     // ... and an epilogue on 32-bit buffer offsets (gemm_common.h): output / residual spans of at most 1 GiB
-    const int64_t c_span = ((int64_t)(a.M - 1) * a.ldc + a.N) * 2, r_span = a.res ? ((int64_t)(a.M - 1) * a.ldr + a.N) * 2 : 0;
+    const int64_t c_span = ((int64_t)((a.oscat ? 4 * (int64_t)a.M : a.M) - 1) * a.ldc + a.N) * 2, r_span = a.res ? ((int64_t)(a.M - 1) * a.ldr + a.N) * 2 : 0;
     const bool dma_ok = a.a1_bytes < (1ll << 31) && a.a2_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) && c_span <= (1ll << 30) && r_span <= (1ll << 30) &&
                         (MODE == 1 ? a.Cin % BK == 0 : (a.K1 == a.K || a.K1 % BK == 0));
     int code = heuristic_code<MODE>(ctx, a, dma_ok);
@@ -615,7 +615,7 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     }
     if (ctx->force_tile) { code = ctx->force_tile % 1000; order = ctx->force_tile >= 2000 ? 1 : ctx->force_tile >= 1000 ? 0 : -1; pinned = true; }
     if (ctx->autotune && !pinned && dma_ok && !ctx->gemm_probe) {      // 1: tune shapes not met before, 2: remembered shapes only
-        const fie_tune_key key{MODE, a.M, a.N, a.K, a.K1, MODE == 1 ? a.stride * 2 + a.ups : 0, a.w_scale != nullptr};
+        const fie_tune_key key{MODE, a.M, a.N, a.K, a.K1, MODE == 1 ? a.stride * 2 + a.ups + 8 * a.taps2 : 0, a.w_scale != nullptr};
         auto it = ctx->tuned.find(key);
         if (it != ctx->tuned.end()) {
             code = it->second;
@@ -858,6 +858,52 @@ int fie_conv3x3_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int C
                          int64_t ldr, float scale, int act) {
     return conv_impl("fie_conv3x3_nhwc_f16", ctx, X, B, H, W, Cin, upsample2x, stride, pad_mode, Wpacked, ldw, nullptr, Y, ldc, Cout, bias,
                      rowbias, ld_rowbias, residual, ldr, scale, act);
+}
+
+// conv3x3(nearest-2x(X)) as four 2x2 convs on X, one per output parity: the three taps of a 3x3 window on the upsampled image fall on TWO
+// input pixels per axis (parity 0: {ky 0} | {ky 1, 2}; parity 1: {ky 0, 1} | {ky 2}), so with the weights of coinciding taps summed
+// beforehand (W4: [4 = py * 2 + px][Npad][ldw], K index = (a * 2 + b) * Cin + ci) 4 instead of 9 multiply-adds per output give the same
+// sums -- zero padding included: an upsampled row is outside the image exactly when its input row is.  2.25x fewer FLOPs on the
+// decoder's / UNet's up-sampling convs.  Each parity is one launch of the ring / phased kernels with a 2x2 tap view (pt = 1 - py,
+// pl = 1 - px) whose epilogue scatters row (b, y, x) to pixel (2y + py, 2x + px).
+int fie_conv_up2x_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, const void* W4, int64_t ldw, int Npad, void* Y, int64_t ldc,
+                           int Cout, const void* bias, const void* rowbias, int64_t ld_rowbias, float scale, int act) {
+    const char* who = "fie_conv_up2x_nhwc_f16";
+    FIE_REQUIRE(ctx && X && W4 && Y, "%s: NULL ctx/X/W/Y", who);
+    FIE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % BK == 0 && Cout > 0 && Npad >= Cout, "%s: bad shape (Cin %% 64 == 0)", who);
+    FIE_REQUIRE(act != FIE_ACT_GEGLU, "%s: GEGLU not supported", who);
+    const int K = 4 * Cin;
+    FIE_REQUIRE(ldw % BK == 0 && ldw >= K, "%s: ldw=%lld must be a multiple of 64 covering 4*Cin", who, (long long)ldw);
+    if (int e = check_epilogue(who, Cout, ldc, nullptr, 0, act)) return e;
+    FIE_REQUIRE((int64_t)B * H * W * 4 < (1ll << 31), "%s: too many output pixels", who);
+    float* gn = ctx->gn_target;                             // GroupNorm sums of the [B, 2H, 2W, Cout] output: a quarter of the granules per parity
+    const int64_t gn_rows = ctx->gn_target_rows;
+    const int gn_groups = ctx->gn_target_groups;
+    ctx->gn_target = nullptr;
+    if (gn) {
+        FIE_REQUIRE(gn_rows == 4ll * H * W && (H * W) % 32 == 0 && Cout % gn_groups == 0, "%s: GroupNorm statistics: %lld rows per image for a %dx%d input", who, (long long)gn_rows, H, W);
+        const int cg = Cout / gn_groups;
+        FIE_REQUIRE(cg == 4 || cg == 8 || cg == 16, "%s: GroupNorm statistics need 4, 8 or 16 channels per group (got %d)", who, cg);
+    }
+    for (int par = 0; par < 4; ++par) {
+        GemmArgs a = {};
+        a.A1 = (const half_t*)X; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W; a.stride = 1;
+        a.taps2 = 1; a.oscat = 1; a.opy = par >> 1; a.opx = par & 1; a.pt = 1 - a.opy; a.pl = 1 - a.opx; a.ups = 0;
+        a.Wt = (const half_t*)W4 + (int64_t)par * Npad * ldw; a.ldw = ldw; a.C = (half_t*)Y; a.ldc = ldc;
+        a.M = B * H * W; a.N = Cout; a.K = K; a.K1 = K;
+        a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
+        a.rows_per_batch = H * W; a.scale = scale; a.act = act;
+        a.a1_bytes = (int64_t)B * H * W * Cin * 2;
+        a.w_bytes = (int64_t)Npad * ldw * 2;
+        if (gn) {
+            a.gn_partial = gn; a.gn_rows = H * W; a.gn_G = gn_groups; a.gn_cg = Cout / gn_groups;
+            a.gn_nch = (int)(gn_rows / 32); a.gn_chunk0 = par * (H * W / 32);
+        }
+        const bool dma_ok = a.a1_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) && ((int64_t)(4ll * a.M - 1) * ldc + Cout) * 2 <= (1ll << 30);
+        FIE_REQUIRE(dma_ok, "%s: tensors too large for the LDS-DMA kernels (use fie_conv3x3_nhwc_f16 with upsample2x)", who);
+        if (int rc = launch<1>(ctx, a)) return rc;
+    }
+    return FIE_OK;
 }
 
 int fie_conv3x3_w8_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, int upsample2x, int stride, int pad_mode,

@@ -76,6 +76,7 @@ SIGNATURES = {
     "fie_debug_tile_override": [_P, _c.c_char_p],
     "fie_debug_last_gemm_kernel": [_P],
     "fie_prefetch": [_P, _P, _L, _P, _I],
+    "fie_conv_up2x_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P, _L, _I, _P, _L, _I, _P, _P, _L, _F, _I],
     "fie_gn_stats_target": [_P, _P, _L, _I],
     "fie_gn_stats_bytes": [_I, _L, _I],
     "fie_groupnorm_stats_nhwc_f16": [_P, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _P],
@@ -196,6 +197,7 @@ class Context:
         self._gn_stats = {}
         self._gn_gen = 0
         self.gn_from_epilogue = os.environ.get("FIE_GN_FROM_EPILOGUE", "1") != "0"
+        self.up2x_parity = os.environ.get("FIE_UP2X_PARITY", "1") != "0"      # 2x-upsampling convs as four 2x2 convs (fie_conv_up2x_nhwc_f16)
         self._resize_tables = {}       # (in, out) -> (taps, bounds, ksize) of the LANCZOS resample, on the device
         self.ws_tag = 0
         self._keep = None              # list collecting the tensors allocated while a program is being recorded (Context.record)
@@ -368,6 +370,30 @@ class Context:
                                 _p(wp), wp.stride(0), _p(out), out.stride(0), m, n, ktot, _p(bias), _p(rowbias),
                                 rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
                                 residual.stride(0) if residual is not None else 0, float(scale), act))
+        out._gn_tag = tag
+        return out
+
+    def pack_conv_up2x(self, w):
+        """OIHW 3x3 weights -> the four parity matrices of fie_conv_up2x_nhwc_f16, [4][Npad][Kpad] f16: for output parity (py, px) the taps
+        that fall on the same input pixel are summed (fp32, rounded once): rows {ky 0} | {ky 1, 2} for parity 0, {ky 0, 1} | {ky 2} for 1."""
+        w = w.to(self.device, torch.float32)
+        sets = (((0,), (1, 2)), ((0, 1), (2,)))
+        mats = []
+        for py in range(2):
+            for px in range(2):
+                taps = [sum(w[:, :, ky, kx] for ky in sets[py][a] for kx in sets[px][b]) for a in range(2) for b in range(2)]    # 4 x [Cout, Cin]
+                mats.append(self.pack_linear(torch.stack(taps, 1).reshape(w.shape[0], -1).to(torch.float16), quant=False))
+        return torch.stack(mats).contiguous()
+
+    def conv_up2x(self, x, wp4, cout, bias=None, rowbias=None, scale=1.0, act=ACT_NONE, gn_groups=None):
+        """conv3x3(nearest-2x(x)) from the four parity matrices of pack_conv_up2x: x [B, H, W, Cin] -> [B, 2H, 2W, cout]."""
+        self.sync_stream()
+        b, h, w, cin = x.shape
+        assert x.is_contiguous() and not self.f32 and cin % 64 == 0
+        out = self._alloc((b, 2 * h, 2 * w, cout))
+        tag = self._gn_stats_arm(b * 4 * h * w, cout, 4 * h * w, gn_groups) if gn_groups else None
+        _chk(lib().fie_conv_up2x_nhwc_f16(self.h, _p(x), b, h, w, cin, _p(wp4), wp4.stride(1), wp4.shape[1], _p(out), out.stride(2), cout,
+                                          _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, float(scale), act))
         out._gn_tag = tag
         return out
 

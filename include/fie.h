@@ -234,6 +234,15 @@ int fie_debug_tile_override(fie_ctx* ctx, const char* spec);       /* "mode,M,N,
  * Every tile accumulates K in the same order, so the choice does not change results.  on = 2 keeps using what is remembered but
  * tunes nothing new and frees the scratch (0.4 GB + one output); on = 0 returns to the built-in rule.  fie_gemm_autotune_report writes one "gemm|conv M= N= K= K1= geom= w8= -> code" line per remembered problem
  * into buf (NUL-terminated, truncated to cap) and returns the number of problems. */
+/* conv3x3 on the nearest-2x upsampled input (upstream models/upsampling.py Upsample2D: F.interpolate(scale_factor=2, mode="nearest") then
+ * conv) computed as four 2x2 convs on the input itself, one per output parity, with the weights of the taps that coincide on one input
+ * pixel summed beforehand: the same sums (zero padding included) from 4 instead of 9 multiply-adds per output.  W4 = the four packed
+ * matrices [py * 2 + px][Npad][ldw] with K index (a * 2 + b) * Cin + ci (fie_amd/hip.py: pack_conv_up2x builds them from the OIHW
+ * weights).  X [B, H, W, Cin] (Cin % 64 == 0) -> Y [B, 2H, 2W, ldc]; epilogue options as fie_conv3x3_nhwc_f16 without a residual; an
+ * armed fie_gn_stats_target (rows_per_image = 4 H W) is honoured.  Differs from the 9-tap form by the f16 rounding of the summed weights. */
+int fie_conv_up2x_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, const void* W4, int64_t ldw, int Npad, void* Y, int64_t ldc,
+                           int Cout, const void* bias, const void* rowbias, int64_t ld_rowbias, float scale, int act);
+
 /* GroupNorm statistics from the producer's epilogue (upstream: the first of the three passes torch.nn.GroupNorm makes over the tensor,
  * models/resnet.py norm1 / norm2, models/autoencoders/vae.py).  fie_gn_stats_target arms the NEXT fie_gemm_f16 / fie_conv3x3_nhwc_f16
  * launch on this context (one shot): besides its output [M, N] it writes, per image (rows_per_image rows, a multiple of 32), per 32-row

@@ -502,6 +502,33 @@ def test_groupnorm_statistics_from_the_producing_conv(fie, cout, code):
     assert rel_err(fie.groupnorm(o4, gamma, beta, groups, 1e-6, False), fie.groupnorm(o4.clone(), gamma, beta, groups, 1e-6, False).float()) < 1e-3
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,code", [(2, 16, 16, 128, 128, 0), (1, 24, 40, 64, 256, 54), (2, 32, 32, 256, 512, 81), (1, 20, 12, 128, 192, 42)])
+def test_upsampling_conv_as_four_parity_convs(fie, b, h, w, cin, cout, code):
+    """fie_conv_up2x_nhwc_f16 (include/fie.h): conv3x3(nearest-2x(x)) from four 2x2 convs with pre-summed taps equals the 9-tap kernel with the
+    upsampling folded into its addressing (up to the f16 rounding of the summed weights) and torch; borders (zero padding of the upsampled
+    image), bias + row bias + SiLU, non-square maps, every tile family; with GroupNorm sums from its epilogue the normalised result
+    matches too."""
+    x = rnd(b, h, w, cin, seed=1).to(DEV)
+    w4d = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    bias, rb = rnd(cout, seed=3).to(DEV), rnd(b, cout, seed=4).to(DEV)
+    wp, wp4 = fie.pack_conv3x3(w4d.to(DEV)), fie.pack_conv_up2x(w4d)
+    from fie_amd import hip
+    fie.force_tile(code)
+    try:
+        nine = fie.conv3x3(x, wp, cout, upsample=True, bias=bias, rowbias=rb, act=hip.ACT_SILU)
+        four = fie.conv_up2x(x, wp4, cout, bias=bias, rowbias=rb, act=hip.ACT_SILU, gn_groups=32 if cout // 32 in (4, 8, 16) and (h * w) % 32 == 0 else None)
+    finally:
+        fie.force_tile(0)
+    up = torch.nn.functional.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(up, w4d.to(DEV).float(), bias.float(), padding=1) + rb.float()[:, :, None, None]
+    ref = torch.nn.functional.silu(ref).permute(0, 2, 3, 1)
+    assert four.shape == nine.shape == ref.shape
+    assert rel_err(four, ref) < 4e-3 and rel_err(four, nine.float()) < 3e-3
+    if four._gn_tag is not None:
+        gamma, beta = (1 + 0.1 * rnd(cout, seed=5)).to(DEV), (0.1 * rnd(cout, seed=6)).to(DEV)
+        assert rel_err(fie.groupnorm(four, gamma, beta, 32, 1e-6, True), fie.groupnorm(four.clone(), gamma, beta, 32, 1e-6, True).float()) < 1e-3
+
+
 def test_time_embed_fused(fie):
     """K7 fused kernel against the unfused route it replaces (embeddings.py): sinusoid -> Linear -> SiLU -> Linear, + the
     text-time embedding, SiLU; SDXL dims (320 -> 1280 -> 1280) and the tiny stack's (64 -> 256), batch 1 / 2 / 4, t = 499 KAT
