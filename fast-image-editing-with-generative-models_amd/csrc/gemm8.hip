@@ -44,7 +44,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = take_parity(p, xcd_remap(blockIdx.x, gridDim.x));
     const int m0 = (p.order ? bid % p.nbm : bid / p.nbn) * 256;
     const int n0 = (p.order ? bid / p.nbm : bid % p.nbn) * 256;
     const int lr = lane >> 3;
@@ -270,7 +270,7 @@ int fie_gemm8_init(void) {
 }
 
 int fie_launch_gemm8(fie_ctx* ctx, const GemmArgs& a, int conv, int split) {
-    const dim3 grid((unsigned)(a.nbm * a.nbn));
+    const dim3 grid((unsigned)(a.nbm * a.nbn * (a.oscat == 2 ? 4 : 1)));
     if (conv && split) fie_launch(ctx, (gemm8_kernel<2, 1>), grid, dim3(512), kLds8, a);
     else if (conv) fie_launch(ctx, (gemm8_kernel<2, 0>), grid, dim3(512), kLds8, a);
     else if (split) fie_launch(ctx, (gemm8_kernel<0, 1>), grid, dim3(512), kLds8, a);

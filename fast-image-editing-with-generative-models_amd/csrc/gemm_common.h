@@ -31,7 +31,8 @@ struct GemmArgs {
     int64_t a1_bytes, a2_bytes, w_bytes;   // operand extents for the v3 buffer descriptors
     // 2x-upsampling conv as four 2x2 convs (fie_conv_up2x_nhwc_f16): taps2 = the conv view has 2x2 taps (K = 4 * Cin) with pt / pl = 1 - parity;
     // oscat = output row m = (b, oh, ow) of the OH x OW view is stored at pixel (2 oh + opy, 2 ow + opx) of the [B, 2 OH, 2 OW] output
-    int taps2, oscat, opy, opx;
+    int taps2, oscat, opy, opx;             // oscat 2: all four parities in ONE launch, tile id = 4 * tile + parity (take_parity below)
+    int64_t w_par_stride;                   // oscat 2: elements between the parity weight matrices
     int gn_nch, gn_chunk0;                  // GroupNorm partials: granules per image in the buffer (0: gn_rows / 32) and this launch's first granule
     float* gn_partial; int gn_rows, gn_G, gn_cg;   // GroupNorm statistics of the OUTPUT (fie_gn_stats_target): per image and 32-row granule [b][gn_rows / 32][gn_G][2] = (sum, sum of squares) of the f16-rounded values, gn_cg = N / gn_G in {4, 8, 16} channels per group; NULL: none
     const float* w_scale;                   // fp8 weights (gemm_w8.hip): per-output-channel dequantisation scale [N], applied to the accumulator first; Wt then points at e4m3 bytes and ldw counts bytes
@@ -39,6 +40,17 @@ struct GemmArgs {
     int probe;                              // timing-only probes (fie_debug_gemm_probe; outputs are wrong): 1 = every DMA load dropped (zero-record descriptors), 2 = every tile fetches tile (0,0)'s operands (all L2 hits), 3 = ring kernels issue no DMA inside the K loop (MFMA + ds_read + barrier floor), 4 = no epilogue (nothing stored)
     int order;                              // 0: n-tiles fastest (an XCD owns a range of rows), 1: m-tiles fastest (an XCD owns a range of columns)
 };
+
+// oscat == 2: the block's parity comes from its (remapped) tile id; the four parity tiles of one output tile are neighbours in time and
+// share the input rows in L2.  Rewrites the by-value kernel argument and returns the tile id within the parity.
+__device__ __forceinline__ int take_parity(GemmArgs& p, int bid) {
+    if (p.oscat != 2) return bid;
+    const int par = bid & 3;
+    p.opy = par >> 1; p.opx = par & 1; p.pt = 1 - p.opy; p.pl = 1 - p.opx;
+    p.Wt += (int64_t)par * p.w_par_stride;
+    p.gn_chunk0 = par * ((p.OH * p.OW) >> 5);
+    return bid >> 2;
+}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
 

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
 
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = take_parity(p, xcd_remap(blockIdx.x, gridDim.x));
     const int m0 = (p.order ? bid % p.nbm : bid / p.nbn) * BM;
     const int n0 = (p.order ? bid / p.nbm : bid % p.nbn) * BN;
     const int lr = lane >> 3;
@@ -476,6 +476,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok) {
         if (d.code == code) t = &d;
     FIE_REQUIRE(t != nullptr, "unknown tile code %d", code);
     FIE_REQUIRE(code < 40 || dma_ok, "tile code %d: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)", code);
+    FIE_REQUIRE(!(a.taps2 && (code < 40 || a.w_scale)), "tile code %d: the 2x2 parity convs run on the f16 LDS-DMA kernels only", code);
     if (order < 0) {
         // Tile order = which operand an XCD re-streams past its 4 MiB L2.  Consecutive tile ids run on one XCD (xcd_remap), so an
         // XCD owns T/8 consecutive tiles: with n fastest that is `dm` row blocks x up to all column tiles, with m fastest the
@@ -508,7 +509,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok) {
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "gemm3w8_kernel<%dx%d> (%s, fp8 weights, tile code %d)", t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
         return fie_launch_gemm_w8(ctx, a, MODE == 1, code);
     }
-    const dim3 grid((unsigned)(a.nbm * a.nbn)), block(256);
+    const dim3 grid((unsigned)(a.nbm * a.nbn * (a.oscat == 2 ? 4 : 1))), block(256);
     constexpr int M3 = MODE == 1 ? 2 : 0;
     switch (code) {
         case 1: fie_launch(ctx, (gemm_kernel<128, 128, MODE>), grid, block, 0, a); break;
@@ -864,8 +865,8 @@ int fie_conv3x3_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int C
 // input pixels per axis (parity 0: {ky 0} | {ky 1, 2}; parity 1: {ky 0, 1} | {ky 2}), so with the weights of coinciding taps summed
 // beforehand (W4: [4 = py * 2 + px][Npad][ldw], K index = (a * 2 + b) * Cin + ci) 4 instead of 9 multiply-adds per output give the same
 // sums -- zero padding included: an upsampled row is outside the image exactly when its input row is.  2.25x fewer FLOPs on the
-// decoder's / UNet's up-sampling convs.  Each parity is one launch of the ring / phased kernels with a 2x2 tap view (pt = 1 - py,
-// pl = 1 - px) whose epilogue scatters row (b, y, x) to pixel (2y + py, 2x + px).
+// decoder's / UNet's up-sampling convs.  A parity is the ring / phased kernels' conv view with 2x2 taps (pt = 1 - py, pl = 1 - px) whose
+// epilogue scatters row (b, y, x) to pixel (2y + py, 2x + px); the four parities share one launch.
 int fie_conv_up2x_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, const void* W4, int64_t ldw, int Npad, void* Y, int64_t ldc,
                            int Cout, const void* bias, const void* rowbias, int64_t ld_rowbias, float scale, int act) {
     const char* who = "fie_conv_up2x_nhwc_f16";
@@ -885,24 +886,24 @@ int fie_conv_up2x_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int
         const int cg = Cout / gn_groups;
         FIE_REQUIRE(cg == 4 || cg == 8 || cg == 16, "%s: GroupNorm statistics need 4, 8 or 16 channels per group (got %d)", who, cg);
     }
-    for (int par = 0; par < 4; ++par) {
-        GemmArgs a = {};
-        a.A1 = (const half_t*)X; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W; a.stride = 1;
-        a.taps2 = 1; a.oscat = 1; a.opy = par >> 1; a.opx = par & 1; a.pt = 1 - a.opy; a.pl = 1 - a.opx; a.ups = 0;
-        a.Wt = (const half_t*)W4 + (int64_t)par * Npad * ldw; a.ldw = ldw; a.C = (half_t*)Y; a.ldc = ldc;
-        a.M = B * H * W; a.N = Cout; a.K = K; a.K1 = K;
-        a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
-        a.rows_per_batch = H * W; a.scale = scale; a.act = act;
-        a.a1_bytes = (int64_t)B * H * W * Cin * 2;
-        a.w_bytes = (int64_t)Npad * ldw * 2;
-        if (gn) {
-            a.gn_partial = gn; a.gn_rows = H * W; a.gn_G = gn_groups; a.gn_cg = Cout / gn_groups;
-            a.gn_nch = (int)(gn_rows / 32); a.gn_chunk0 = par * (H * W / 32);
-        }
-        const bool dma_ok = a.a1_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) && ((int64_t)(4ll * a.M - 1) * ldc + Cout) * 2 <= (1ll << 30);
-        FIE_REQUIRE(dma_ok, "%s: tensors too large for the LDS-DMA kernels (use fie_conv3x3_nhwc_f16 with upsample2x)", who);
-        if (int rc = launch<1>(ctx, a)) return rc;
+    // ONE launch for the four parities: tile id = 4 * tile + parity (gemm_common.h: take_parity), so the four parity tiles of an output tile
+    // run together and share their input rows in L2, and the small up-sampler convs of the UNet fill the CUs (160 tiles per parity otherwise)
+    GemmArgs a = {};
+    a.A1 = (const half_t*)X; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W; a.stride = 1;
+    a.taps2 = 1; a.oscat = 2; a.pt = a.pl = 1; a.ups = 0;
+    a.Wt = (const half_t*)W4; a.w_par_stride = (int64_t)Npad * ldw; a.ldw = ldw; a.C = (half_t*)Y; a.ldc = ldc;
+    a.M = B * H * W; a.N = Cout; a.K = K; a.K1 = K;
+    a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
+    a.rows_per_batch = H * W; a.scale = scale; a.act = act;
+    a.a1_bytes = (int64_t)B * H * W * Cin * 2;
+    a.w_bytes = (int64_t)Npad * ldw * 2;                    // per parity: the kernel's descriptor starts at its own matrix
+    if (gn) {
+        a.gn_partial = gn; a.gn_rows = H * W; a.gn_G = gn_groups; a.gn_cg = Cout / gn_groups;
+        a.gn_nch = (int)(gn_rows / 32);
     }
+    const bool dma_ok = a.a1_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) && ((int64_t)(4ll * a.M - 1) * ldc + Cout) * 2 <= (1ll << 30);
+    FIE_REQUIRE(dma_ok, "%s: tensors too large for the LDS-DMA kernels (use fie_conv3x3_nhwc_f16 with upsample2x)", who);
+    if (int rc = launch<1>(ctx, a)) return rc;
     return FIE_OK;
 }
 
