@@ -568,8 +568,8 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     t.C = static_cast<half_t*>(ctx->tune_buf);           // a residual that aliases C is still read from the caller's buffer
     auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
     auto time_of = [&](int code) -> float {
-        float ms[5];
-        for (int rep = -1; rep < 5; ++rep) {               // rep -1: untimed (first use of the kernel)
+        float ms[7];
+        for (int rep = -1; rep < 7; ++rep) {               // rep -1: untimed (first use of the kernel)
             (void)hipMemsetAsync(ctx->tune_flush, rep & 1, kFlushBytes, ctx->stream);
             if ((size_t)a.a1_bytes <= kFlushBytes) (void)hipMemcpyAsync(ctx->tune_flush, a.A1, (size_t)a.a1_bytes, hipMemcpyDeviceToDevice, ctx->stream);
             if (a.A2 && a.A2 != a.A1 && (size_t)a.a2_bytes <= kFlushBytes) (void)hipMemcpyAsync(ctx->tune_flush, a.A2, (size_t)a.a2_bytes, hipMemcpyDeviceToDevice, ctx->stream);
@@ -579,8 +579,8 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
             if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
             if (rep >= 0) (void)hipEventElapsedTime(&ms[rep], e0, e1);
         }
-        std::sort(ms, ms + 5);
-        return ms[2];
+        std::sort(ms, ms + 7);
+        return (ms[2] + ms[3] + ms[4]) / 3.f;              // mean of the middle three of seven
     };
     const float t_guess = time_of(guess);
     int best = guess;
