@@ -582,7 +582,9 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
         std::sort(ms, ms + 7);
         return (ms[2] + ms[3] + ms[4]) / 3.f;              // mean of the middle three of seven
     };
+    static const bool verbose = getenv("FIE_TUNE_VERBOSE") && getenv("FIE_TUNE_VERBOSE")[0] == '1';
     const float t_guess = time_of(guess);
+    if (verbose) fprintf(stderr, "[fie tune] %s M=%d N=%d K=%d: rule %d %.1f us", MODE == 1 ? "conv" : "gemm", a.M, a.N, a.K, guess, t_guess * 1e3f);
     int best = guess;
     float t_best = t_guess * 0.97f;                          // a challenger has to win by 3 %
     const int* cand = a.w_scale ? kW8 : kRing;
@@ -593,8 +595,10 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
         if ((c == 43 || c == 46) && blocks(64, 64) > 64 * ctx->num_cus) continue;       // tens of thousands of tiny tiles: never wins
         if ((c == 81 || c == 96 || c == 62) && 2 * blocks(256, 128) < ctx->num_cus) continue;
         const float tc = time_of(c);
+        if (verbose) fprintf(stderr, ", %d %.1f", c, tc * 1e3f);
         if (tc < t_best) { t_best = tc; best = c; }
     }
+    if (verbose) fprintf(stderr, " -> %d\n", best);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return best;
