@@ -144,15 +144,15 @@ int fie_canny_rgb_device_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int 
     for (;;) {
         int h = 0;
         if (hipMemsetAsync(flag, 0, sizeof(int), ctx->stream) != hipSuccess) { fie_set_error("fie_canny_rgb_device_u8: memset failed"); return FIE_EHIP; }
-        fie_launch(ctx, canny_hyst_kernel, hgrid, dim3(256), 0, map, H, W, flag);
-        fie_launch(ctx, canny_hyst_kernel, hgrid, dim3(256), 0, map, H, W, flag);
+        for (int rep = 0; rep < 4; ++rep)                   // four passes per read-back: a pass past the fixed point changes nothing, a host round trip costs more than a pass
+            fie_launch(ctx, canny_hyst_kernel, hgrid, dim3(256), 0, map, H, W, flag);
         FIE_LAUNCH_CHECK();
         if (hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
             fie_set_error("fie_canny_rgb_device_u8: flag read-back failed");
             return FIE_EHIP;
         }
-        iters += 2;
+        iters += 4;
         if (!h) break;
         if (iters > max_iters) { fie_set_error("fie_canny_rgb_device_u8: hysteresis did not converge in %d passes", iters); return FIE_EHIP; }
     }
