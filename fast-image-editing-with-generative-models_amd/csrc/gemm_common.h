@@ -18,6 +18,9 @@ constexpr int BK = 64;
 struct GemmArgs {
     const half_t* A1; int64_t lda1; int K1;
     const half_t* A2; int64_t lda2;
+    // conv view with 1x1 side inputs (fie_conv3x3_plus_nhwc_f16: a resnet's conv2 + its 1x1 shortcut in one GEMM): after the taps, K-steps
+    // C2x / 64 read row m of A2 and C3x / 64 row m of A3 (the shortcut's input, or its two halves [x | skip])
+    const half_t* A3; int64_t lda3; int C2x, C3x; int64_t a3_bytes;
     // conv view of A1
     int H, W, Cin, OH, OW, stride, pt, pl, ups;
     const half_t* Wt; int64_t ldw;

@@ -192,10 +192,12 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)p.a1_bytes * live, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, (int)p.a2_bytes * live, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, (int)p.w_bytes * live, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A3, 0, (int)p.a3_bytes * live, 0x00020000);
     const int lm0 = p.probe == 2 ? 0 : m0, ln0 = p.probe == 2 ? 0 : n0;
 
     // per-lane byte offsets
-    unsigned a_off1[RA], a_off2[RA];       // GEMM: row offsets into A1 / A2;  conv: a_off1 = offset for the current tap
+    unsigned a_off1[RA], a_off2[RA];       // GEMM: row offsets into A1 / A2;  conv: a_off1 = offset for the current tap, a_off2 = row m of the side input A2
+    unsigned a_off3[RA];                   // conv: row m of the second side input A3
     int a_ih[RA], a_iw[RA];
     unsigned a_img[RA];
     bool a_ok[RA];
@@ -211,12 +213,14 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             a_iw[i] = ow * p.stride - p.pl;
             a_img[i] = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.Cin * 2u;
             a_off1[i] = kOob;
-            a_off2[i] = 0;
+            a_off2[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda2 * 2u + c8 * 16u : kOob;
+            a_off3[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda3 * 2u + c8 * 16u : kOob;
         } else {
             a_off1[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda1 * 2u + c8 * 16u : kOob;
             a_off2[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda2 * 2u + c8 * 16u : kOob;
             a_ih[i] = a_iw[i] = 0;
             a_img[i] = 0;
+            a_off3[i] = 0;
         }
     }
     unsigned w_off[RW];
@@ -229,9 +233,19 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     const int nk = (p.K + BK - 1) / BK;
     const bool ktail = (p.K % BK) != 0;
 
+    const int ntaps = p.taps2 ? 4 : 9;
     auto issue = [&](int kt, int stage) {
         half_t* sa = smem + stage * STAGE;
-        if (MODE == 2) {
+        if (MODE == 2 && ftap >= ntaps) {                   // past the taps: the 1x1 side inputs, row m itself
+            const int e = kt - ntaps * csteps, x2 = p.C2x / BK;
+            if (e < x2) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a2, sa + (wave + NW * i) * 512, a_off2[i], (unsigned)e * (BK * 2));
+            } else {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) bload16(rs_a3, sa + (wave + NW * i) * 512, a_off3[i], (unsigned)(e - x2) * (BK * 2));
+            }
+        } else if (MODE == 2) {
             if (cs == 0) {
                 const int ky = p.taps2 ? ftap >> 1 : (ftap * 11) >> 5, kx = p.taps2 ? ftap & 1 : ftap - 3 * ky;
                 const int hlim = p.H << p.ups, wlim = p.W << p.ups;
@@ -446,8 +460,8 @@ int heuristic_code(const fie_ctx* ctx, const GemmArgs& a, bool dma_ok) {
     if (!dma_ok) {
         code = b42 >= cus ? 2 : 3;
     } else if (MODE == 1) {
-        if ((b256 >= cus && (a.N % 256 == 0 || (a.N % 128 != 0 && a.K >= 5760))) ||        // 256x256 phased: VAE 256/512-ch maps, 128x128-latent convs into 320 ch
-            (a.N % 256 == 0 && a.K >= 8192 && 2 * b256 >= cus)) code = 81;                  // ... and the long-K upsampling convs of the 32x32 level
+        if (!a.A2 && ((b256 >= cus && (a.N % 256 == 0 || (a.N % 128 != 0 && a.K >= 5760))) ||        // 256x256 phased: VAE 256/512-ch maps, 128x128-latent convs into 320 ch (not with 1x1 side inputs: ring kernels only)
+            (a.N % 256 == 0 && a.K >= 8192 && 2 * b256 >= cus))) code = 81;                  // ... and the long-K upsampling convs of the 32x32 level
         else if (a.N % 128 == 0 && b62 >= 150) code = 96;
         else if (a.N % 128 == 0 && a.K >= 5760 && b51 >= 100) code = 51;                     // 32x32-latent convs: 160 x (128x128), 8 waves
         else if (2 * b42 < 3 * cus) code = 43;                                               // stride-2 convs and other small grids
@@ -477,6 +491,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok) {
     FIE_REQUIRE(t != nullptr, "unknown tile code %d", code);
     FIE_REQUIRE(code < 40 || dma_ok, "tile code %d: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)", code);
     FIE_REQUIRE(!(a.taps2 && (code < 40 || a.w_scale)), "tile code %d: the 2x2 parity convs run on the f16 LDS-DMA kernels only", code);
+    FIE_REQUIRE(!(MODE == 1 && a.A2 && (code < 40 || code == 81 || code == 82 || a.w_scale)), "tile code %d: conv + 1x1 side inputs run on the f16 ring kernels only", code);
     if (order < 0) {
         // Tile order = which operand an XCD re-streams past its 4 MiB L2.  Consecutive tile ids run on one XCD (xcd_remap), so an
         // XCD owns T/8 consecutive tiles: with n fastest that is `dm` row blocks x up to all column tiles, with m fastest the
@@ -594,6 +609,7 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
         if (c == guess) continue;
         if ((c == 43 || c == 46) && blocks(64, 64) > 64 * ctx->num_cus) continue;       // tens of thousands of tiny tiles: never wins
         if ((c == 81 || c == 96 || c == 62) && 2 * blocks(256, 128) < ctx->num_cus) continue;
+        if (c == 81 && MODE == 1 && a.A2) continue;            // side inputs: ring kernels only
         const float tc = time_of(c);
         if (verbose) fprintf(stderr, ", %d %.1f", c, tc * 1e3f);
         if (tc < t_best) { t_best = tc; best = c; }
@@ -611,6 +627,7 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     const int64_t c_span = ((int64_t)((a.oscat ? 4 * (int64_t)a.M : a.M) - 1) * a.ldc + a.N) * 2, r_span = a.res ? ((int64_t)(a.M - 1) * a.ldr + a.N) * 2 : 0;
     const bool dma_ok = a.a1_bytes < (1ll << 31) && a.a2_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) && c_span <= (1ll << 30) && r_span <= (1ll << 30) &&
                         (MODE == 1 ? a.Cin % BK == 0 : (a.K1 == a.K || a.K1 % BK == 0));
+    FIE_REQUIRE(!(MODE == 1 && a.A2 && !dma_ok), "conv + 1x1 side inputs: tensors too large for the LDS-DMA kernels");
     int code = heuristic_code<MODE>(ctx, a, dma_ok);
     int order = -1;                // 0: n-tiles fastest (an XCD owns a range of activation rows), 1: m-tiles fastest; -1: estimate
     bool pinned = false;
@@ -620,7 +637,7 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     }
     if (ctx->force_tile) { code = ctx->force_tile % 1000; order = ctx->force_tile >= 2000 ? 1 : ctx->force_tile >= 1000 ? 0 : -1; pinned = true; }
     if (ctx->autotune && !pinned && dma_ok && !ctx->gemm_probe) {      // 1: tune shapes not met before, 2: remembered shapes only
-        const fie_tune_key key{MODE, a.M, a.N, a.K, a.K1, MODE == 1 ? a.stride * 2 + a.ups + 8 * a.taps2 : 0, a.w_scale != nullptr};
+        const fie_tune_key key{MODE, a.M, a.N, a.K, a.K1, MODE == 1 ? a.stride * 2 + a.ups + 8 * a.taps2 + 16 * (a.A2 != nullptr) + 32 * (a.A3 != nullptr) : 0, a.w_scale != nullptr};
         auto it = ctx->tuned.find(key);
         if (it != ctx->tuned.end()) {
             code = it->second;
@@ -828,15 +845,18 @@ int fie_gemm_w8_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const vo
 
 static int conv_impl(const char* who, fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, int upsample2x, int stride, int pad_mode,
                      const void* Wpacked, int64_t ldw, const float* w_scale, void* Y, int64_t ldc, int Cout, const void* bias,
-                     const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ldr, float scale, int act) {
+                     const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ldr, float scale, int act,
+                     const void* X2 = nullptr, int64_t ld2 = 0, int C2 = 0, const void* X3 = nullptr, int64_t ld3 = 0, int C3 = 0) {
     FIE_REQUIRE(ctx && X && Wpacked && Y, "%s: NULL ctx/X/W/Y", who);
     FIE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "%s: bad shape", who);
     FIE_REQUIRE(Cin % 8 == 0, "%s: Cin=%d must be a multiple of 8 (pad the tensor)", who, Cin);
     FIE_REQUIRE(stride == 1 || stride == 2, "%s: stride %d", who, stride);
     FIE_REQUIRE(pad_mode == 0 || pad_mode == 1, "%s: pad_mode %d", who, pad_mode);
     FIE_REQUIRE(act != FIE_ACT_GEGLU, "%s: GEGLU not supported", who);
-    const int K = 9 * Cin;
-    FIE_REQUIRE(ldw % BK == 0 && ldw >= K, "%s: ldw=%lld must be a multiple of 64 covering 9*Cin", who, (long long)ldw);
+    FIE_REQUIRE((X2 != nullptr) == (C2 > 0) && (X3 != nullptr) == (C3 > 0) && (!X3 || X2) && C2 % BK == 0 && C3 % BK == 0 && (!X2 || (Cin % BK == 0 && !w_scale && ld2 >= C2 && (!X3 || ld3 >= C3))),
+                "%s: side inputs need Cin, C2, C3 %% 64 == 0 (C2=%d C3=%d)", who, C2, C3);
+    const int K = 9 * Cin + C2 + C3;
+    FIE_REQUIRE(ldw % BK == 0 && ldw >= K, "%s: ldw=%lld must be a multiple of 64 covering 9*Cin (+ side inputs)", who, (long long)ldw);
     if (int e = check_epilogue(who, Cout, ldc, residual, ldr, act)) return e;
     const int ups = upsample2x ? 1 : 0;
     const int Hin = H << ups, Win = W << ups;
@@ -852,6 +872,12 @@ static int conv_impl(const char* who, fie_ctx* ctx, const void* X, int B, int H,
     a.rows_per_batch = OH * OW; a.res = (const half_t*)residual; a.ldr = ldr; a.scale = scale; a.act = act;
     a.a1_bytes = (int64_t)B * H * W * Cin * 2;
     a.a2_bytes = 0;
+    if (X2) {                                               // 1x1 side inputs: row m of X2 (and X3) after the nine taps
+        FIE_REQUIRE(stride == 1 && !ups && pad_mode == 0, "%s: side inputs need the plain same-size conv", who);
+        a.A2 = (const half_t*)X2; a.lda2 = ld2; a.C2x = C2; a.a2_bytes = ((int64_t)(a.M - 1) * ld2 + C2) * 2;
+        a.A3 = (const half_t*)X3; a.lda3 = ld3; a.C3x = C3; a.a3_bytes = X3 ? ((int64_t)(a.M - 1) * ld3 + C3) * 2 : 0;
+        FIE_REQUIRE(a.a2_bytes < (1ll << 31) && a.a3_bytes < (1ll << 31), "%s: side inputs too large", who);
+    }
     a.w_bytes = fie_roundup(Cout, 128) * ldw * (w_scale ? 1 : 2);
     if (int rc = take_gn_target(who, ctx, a)) return rc;
     return launch<1>(ctx, a);
@@ -863,6 +889,16 @@ int fie_conv3x3_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int C
                          int64_t ldr, float scale, int act) {
     return conv_impl("fie_conv3x3_nhwc_f16", ctx, X, B, H, W, Cin, upsample2x, stride, pad_mode, Wpacked, ldw, nullptr, Y, ldc, Cout, bias,
                      rowbias, ld_rowbias, residual, ldr, scale, act);
+}
+
+// conv3x3(X) + [X2 | X3] W1x1^T in one GEMM: a resnet's second conv together with its 1x1 shortcut (upstream models/resnet.py:
+// conv2(h) + conv_shortcut(input)).  Wpacked rows are [9 * Cin taps | C2 | C3] wide; the separate shortcut GEMM, its [M, Cout] output and
+// the residual read of it disappear, and the sum stays in fp32 until the one rounding.
+int fie_conv3x3_plus_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, const void* Wpacked, int64_t ldw, void* Y, int64_t ldc, int Cout,
+                              const void* bias, const void* rowbias, int64_t ld_rowbias, float scale, int act, const void* X2, int64_t ld2, int C2,
+                              const void* X3, int64_t ld3, int C3) {
+    return conv_impl("fie_conv3x3_plus_nhwc_f16", ctx, X, B, H, W, Cin, 0, 1, 0, Wpacked, ldw, nullptr, Y, ldc, Cout, bias, rowbias, ld_rowbias, nullptr, 0,
+                     scale, act, X2, ld2, C2, X3, ld3, C3);
 }
 
 // conv3x3(nearest-2x(X)) as four 2x2 convs on X, one per output parity: the three taps of a 3x3 window on the upsampled image fall on TWO

@@ -76,6 +76,7 @@ SIGNATURES = {
     "fie_debug_tile_override": [_P, _c.c_char_p],
     "fie_debug_last_gemm_kernel": [_P],
     "fie_prefetch": [_P, _P, _L, _P, _I],
+    "fie_conv3x3_plus_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P, _P, _L, _F, _I, _P, _L, _I, _P, _L, _I],
     "fie_conv_up2x_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P, _L, _I, _P, _L, _I, _P, _P, _L, _F, _I],
     "fie_gn_stats_target": [_P, _P, _L, _I],
     "fie_gn_stats_bytes": [_I, _L, _I],
@@ -197,7 +198,8 @@ class Context:
         self._gn_stats = {}
         self._gn_gen = 0
         self.gn_from_epilogue = os.environ.get("FIE_GN_FROM_EPILOGUE", "1") != "0"
-        self.up2x_parity = os.environ.get("FIE_UP2X_PARITY", "1") != "0"      # 2x-upsampling convs as four 2x2 convs (fie_conv_up2x_nhwc_f16)
+        self.up2x_parity = os.environ.get("FIE_UP2X_PARITY", "1") != "0"
+        self.conv_plus_shortcut = os.environ.get("FIE_CONV_PLUS", "1") != "0"   # resnet conv2 + 1x1 shortcut as one GEMM (fie_conv3x3_plus_nhwc_f16)      # 2x-upsampling convs as four 2x2 convs (fie_conv_up2x_nhwc_f16)
         self._resize_tables = {}       # (in, out) -> (taps, bounds, ksize) of the LANCZOS resample, on the device
         self.ws_tag = 0
         self._keep = None              # list collecting the tensors allocated while a program is being recorded (Context.record)
@@ -370,6 +372,19 @@ class Context:
                                 _p(wp), wp.stride(0), _p(out), out.stride(0), m, n, ktot, _p(bias), _p(rowbias),
                                 rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
                                 residual.stride(0) if residual is not None else 0, float(scale), act))
+        out._gn_tag = tag
+        return out
+
+    def conv3x3_plus(self, x, wp, cout, x2, x3=None, bias=None, rowbias=None, scale=1.0, act=ACT_NONE, gn_groups=None):
+        """conv3x3(x) + [x2 | x3] @ W1x1^T in one GEMM (include/fie.h: fie_conv3x3_plus_nhwc_f16); x2 / x3: [B*H*W, C] views, last dim contiguous."""
+        self.sync_stream()
+        b, h, w, cin = x.shape
+        assert x.is_contiguous() and not self.f32 and x2.stride(1) == 1 and (x3 is None or x3.stride(1) == 1)
+        out = self._alloc((b, h, w, cout))
+        tag = self._gn_stats_arm(b * h * w, cout, h * w, gn_groups) if gn_groups else None
+        _chk(lib().fie_conv3x3_plus_nhwc_f16(self.h, _p(x), b, h, w, cin, _p(wp), wp.stride(0), _p(out), out.stride(2), cout, _p(bias), _p(rowbias),
+                                             rowbias.stride(0) if rowbias is not None else 0, float(scale), act, _p(x2), x2.stride(0), x2.shape[1],
+                                             _p(x3), x3.stride(0) if x3 is not None else 0, x3.shape[1] if x3 is not None else 0))
         out._gn_tag = tag
         return out
 

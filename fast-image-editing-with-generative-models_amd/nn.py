@@ -84,6 +84,14 @@ class Resnet:
         self.c1, self.c2 = Conv3(ctx, sd, p + "conv1"), Conv3(ctx, sd, p + "conv2")
         self.sc = Linear(ctx, sd, p + "conv_shortcut") if p + "conv_shortcut.weight" in sd else None
         self.temb_slot = temb_slot              # (col0, col1) into the fused time-embedding projection
+        # conv2 + the 1x1 shortcut as ONE GEMM (fie_conv3x3_plus_nhwc_f16): conv2's packed matrix with the shortcut's columns appended
+        self.wp_plus = None
+        if self.sc is not None and torch.is_tensor(self.c2.wp) and torch.is_tensor(self.sc.wp) and self.c2.wp.dtype == torch.float16:
+            k2, ksc = 9 * self.c2.cin_pad, sd[p + "conv_shortcut.weight"].shape[1]
+            if self.c2.cin % 64 == 0 and self.c2.cin_pad == self.c2.cin and ksc % 64 == 0 and self.c2.n == self.c2.cout == self.sc.n and self.c2.ldc <= self.c2.n:
+                self.wp_plus = torch.cat([self.c2.wp[:, :k2], self.sc.wp[:, :ksc]], 1).contiguous()
+                zero = torch.zeros(self.c2.n, dtype=self.c2.wp.dtype, device=self.c2.wp.device)
+                self.b_plus = (self.c2.b if self.c2.b is not None else zero) + (self.sc.b if self.sc.b is not None else zero)
 
     def __call__(self, ctx, x, temb_all=None, skip=None):
         b, h, w, _ = x.shape
@@ -91,6 +99,9 @@ class Resnet:
         rb = temb_all[:, self.temb_slot[0]:self.temb_slot[1]] if self.temb_slot is not None else None
         y = self.c1(ctx, y, rowbias=rb, gn_groups=self.groups)          # norm2's first pass rides on conv1's epilogue where the group width allows
         y = ctx.groupnorm(y, self.n2.g, self.n2.b, self.groups, self.eps, True)
+        if self.wp_plus is not None and ctx.conv_plus_shortcut and x.shape[-1] % 64 == 0 and (skip is None or skip.shape[-1] % 64 == 0):
+            return ctx.conv3x3_plus(y, self.wp_plus, self.c2.n, x.view(b * h * w, -1), None if skip is None else skip.view(b * h * w, -1),
+                                    bias=self.b_plus, gn_groups=self.groups)
         if self.sc is not None:
             res = self.sc(ctx, x.view(b * h * w, -1), a2=None if skip is None else skip.view(b * h * w, -1))
             res = res.view(b, h, w, -1)

@@ -234,6 +234,15 @@ int fie_debug_tile_override(fie_ctx* ctx, const char* spec);       /* "mode,M,N,
  * Every tile accumulates K in the same order, so the choice does not change results.  on = 2 keeps using what is remembered but
  * tunes nothing new and frees the scratch (0.4 GB + one output); on = 0 returns to the built-in rule.  fie_gemm_autotune_report writes one "gemm|conv M= N= K= K1= geom= w8= -> code" line per remembered problem
  * into buf (NUL-terminated, truncated to cap) and returns the number of problems. */
+/* A resnet's second conv together with its 1x1 shortcut (upstream models/resnet.py ResnetBlock2D.forward: conv2(h) + conv_shortcut(input))
+ * as ONE GEMM: Y = conv3x3(X) + [X2 | X3] W1x1^T (+ bias, row bias, activation), Wpacked rows = [9 * Cin taps | C2 | C3] (the conv's packed
+ * matrix with the shortcut's columns appended; bias = the two biases added).  X [B, H, W, Cin]; X2 [B*H*W, C2] and the optional X3
+ * [B*H*W, C3] (row strides ld2 / ld3) are the shortcut's input, or its two halves when that is a concat [x | skip]; Cin, C2, C3 % 64 == 0.
+ * The shortcut GEMM, its [M, Cout] output and the residual read disappear; the sum is rounded once. */
+int fie_conv3x3_plus_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, const void* Wpacked, int64_t ldw, void* Y, int64_t ldc, int Cout,
+                              const void* bias, const void* rowbias, int64_t ld_rowbias, float scale, int act, const void* X2, int64_t ld2, int C2,
+                              const void* X3, int64_t ld3, int C3);
+
 /* conv3x3 on the nearest-2x upsampled input (upstream models/upsampling.py Upsample2D: F.interpolate(scale_factor=2, mode="nearest") then
  * conv) computed as four 2x2 convs on the input itself, one per output parity, with the weights of the taps that coincide on one input
  * pixel summed beforehand: the same sums (zero padding included) from 4 instead of 9 multiply-adds per output.  W4 = the four packed

@@ -529,6 +529,35 @@ def test_upsampling_conv_as_four_parity_convs(fie, b, h, w, cin, cout, code):
         assert rel_err(fie.groupnorm(four, gamma, beta, 32, 1e-6, True), fie.groupnorm(four.clone(), gamma, beta, 32, 1e-6, True).float()) < 1e-3
 
 
+@pytest.mark.parametrize("b,hw,cin,c2,c3,cout,code", [(2, 16, 128, 64, 0, 128, 0), (2, 32, 128, 192, 64, 256, 54), (1, 24, 64, 128, 128, 320, 42), (2, 16, 256, 128, 0, 192, 96)])
+def test_conv3x3_with_its_1x1_shortcut_in_one_gemm(fie, b, hw, cin, c2, c3, cout, code):
+    """fie_conv3x3_plus_nhwc_f16 (include/fie.h): conv2(h) + conv_shortcut([x | skip]) of a resnet as one GEMM equals the conv with the shortcut
+    GEMM's output as residual (the unfused route) and torch; one or two side inputs, a side input that is a column slice of a wider tensor
+    (row stride > C2), bias + SiLU, ragged N, the ring tile families."""
+    from fie_amd import hip
+    h = rnd(b, hw, hw, cin, seed=1).to(DEV)
+    wide = rnd(b * hw * hw, c2 + 64, seed=2).to(DEV)
+    x2 = wide[:, 32:32 + c2]                                   # a view: ld2 = c2 + 64
+    x3 = rnd(b * hw * hw, c3, seed=3).to(DEV) if c3 else None
+    wc, wsc = rnd(cout, cin, 3, 3, seed=4, scale=(9 * cin) ** -0.5), rnd(cout, c2 + c3, seed=5, scale=(c2 + c3) ** -0.5)
+    bc, bsc = rnd(cout, seed=6).to(DEV), rnd(cout, seed=7).to(DEV)
+    wp_c, wp_s = fie.pack_conv3x3(wc.to(DEV)), fie.pack_linear(wsc.to(DEV))
+    wp = torch.cat([wp_c[:, :9 * cin], wp_s[:, :c2 + c3]], 1).contiguous()
+    fie.force_tile(code)
+    try:
+        fused = fie.conv3x3_plus(h, wp, cout, x2, x3, bias=bc + bsc, act=hip.ACT_SILU)
+    finally:
+        fie.force_tile(0)
+    xcat = torch.cat([x2, x3], 1) if c3 else x2
+    ref = torch.nn.functional.conv2d(h.float().permute(0, 3, 1, 2), wc.to(DEV).float(), bc.float(), padding=1).permute(0, 2, 3, 1)
+    ref = torch.nn.functional.silu(ref + (xcat.float() @ wsc.to(DEV).float().T + bsc.float()).view(b, hw, hw, cout))
+    assert rel_err(fused, ref) < 4e-3
+    res = fie.gemm(x2, wp_s, cout, a2=x3, bias=bsc).view(b, hw, hw, cout)
+    # the unfused route adds the residual AFTER the activation, so compare it without one
+    plain = fie.conv3x3(h, wp_c, cout, bias=bc, residual=res)
+    assert rel_err(fie.conv3x3_plus(h, wp, cout, x2, x3, bias=bc + bsc), plain.float()) < 3e-3
+
+
 def test_time_embed_fused(fie):
     """K7 fused kernel against the unfused route it replaces (embeddings.py): sinusoid -> Linear -> SiLU -> Linear, + the
     text-time embedding, SiLU; SDXL dims (320 -> 1280 -> 1280) and the tiny stack's (64 -> 256), batch 1 / 2 / 4, t = 499 KAT
