@@ -51,9 +51,12 @@ class Conv3:
         self.ldc = cout_pad or self.cout
         self.n = (self.cout + 3) // 4 * 4          # kernel writes whole 4-channel groups (extra ones are zeros)
         self.wp = ctx.pack_conv3x3(w, self.cin_pad)
-        # up-sampler convs (diffusers: "...upsamplers.0.conv") can run as four 2x2 parity convs: keep the weights for the lazy pack
-        self._w_up = w if "upsamplers" in name and self.cin % 64 == 0 and self.cin_pad == self.cin else None
+        # up-sampler convs (diffusers: "...upsamplers.0.conv") run as four 2x2 parity convs (hip.py: pack_conv_up2x).  Packed HERE, not at
+        # the first call: a first call inside a launch-program recording would record the pack launches instead of running them.
         self.wp4 = None
+        if ("upsamplers" in name and self.cin % 64 == 0 and self.cin_pad == self.cin and ctx.up2x_parity and not ctx.f32
+                and torch.is_tensor(self.wp) and self.ldc <= self.n == self.cout):
+            self.wp4 = ctx.pack_conv_up2x(w)
         b = sd.get(name + ".bias")
         if b is not None:
             bb = torch.zeros(self.n, dtype=ctx.dtype, device=ctx.device)
@@ -63,10 +66,7 @@ class Conv3:
 
     def __call__(self, ctx, x, stride=1, pad_mode=0, upsample=False, rowbias=None, residual=None, act=hip.ACT_NONE, gn_groups=None):
         """gn_groups: the output feeds a GroupNorm with that many groups -- have the epilogue leave its partial sums (hip.py: _gn_stats_arm)."""
-        if (upsample and self._w_up is not None and ctx.up2x_parity and not ctx.f32 and not isinstance(self.wp, hip.W8) and residual is None
-                and stride == 1 and pad_mode == 0 and self.ldc <= self.n == self.cout):
-            if self.wp4 is None:
-                self.wp4 = ctx.pack_conv_up2x(self._w_up)
+        if upsample and self.wp4 is not None and ctx.up2x_parity and residual is None and stride == 1 and pad_mode == 0:
             return ctx.conv_up2x(x, self.wp4, self.n, bias=self.b, rowbias=rowbias, act=act, gn_groups=gn_groups)
         return ctx.conv3x3(x, self.wp, self.n, stride=stride, pad_mode=pad_mode, upsample=upsample, bias=self.b,
                            rowbias=rowbias, residual=residual, act=act, ldc=max(self.ldc, self.n), gn_groups=gn_groups)

@@ -529,7 +529,9 @@ def test_upsampling_conv_as_four_parity_convs(fie, b, h, w, cin, cout, code):
         assert rel_err(fie.groupnorm(four, gamma, beta, 32, 1e-6, True), fie.groupnorm(four.clone(), gamma, beta, 32, 1e-6, True).float()) < 1e-3
 
 
-@pytest.mark.parametrize("b,hw,cin,c2,c3,cout,code", [(2, 16, 128, 64, 0, 128, 0), (2, 32, 128, 192, 64, 256, 54), (1, 24, 64, 128, 128, 320, 42), (2, 16, 256, 128, 0, 192, 96)])
+@pytest.mark.parametrize("b,hw,cin,c2,c3,cout,code", [(2, 16, 128, 64, 0, 128, 0), (2, 32, 128, 192, 64, 256, 54), (1, 24, 64, 128, 128, 320, 42), (2, 16, 256, 128, 0, 192, 96),
+                                                    (2, 16, 64, 64, 64, 128, 43), (2, 16, 64, 64, 64, 128, 44), (2, 16, 64, 64, 64, 128, 46), (2, 16, 64, 64, 64, 128, 51),
+                                                    (2, 16, 64, 64, 64, 128, 52), (2, 16, 64, 64, 64, 128, 95), (2, 16, 64, 64, 64, 128, 62), (2, 16, 64, 64, 64, 128, 61)])
 def test_conv3x3_with_its_1x1_shortcut_in_one_gemm(fie, b, hw, cin, c2, c3, cout, code):
     """fie_conv3x3_plus_nhwc_f16 (include/fie.h): conv2(h) + conv_shortcut([x | skip]) of a resnet as one GEMM equals the conv with the shortcut
     GEMM's output as residual (the unfused route) and torch; one or two side inputs, a side input that is a column slice of a wider tensor
