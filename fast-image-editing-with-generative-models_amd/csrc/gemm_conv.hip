@@ -435,6 +435,8 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
 //   42 / 43        gemm3_kernel  128x64 / 64x64, 3 stages, 4 waves (two / three blocks per CU)
 //   44 / 46        the same tiles with 2 stages (three / five blocks per CU)
 //   52 / 54        gemm3_kernel  128x128 / 192x128, 2 stages, 8 waves: two blocks per CU
+//   47             gemm3_kernel  128x96, 3 stages, 4 waves: 224 tiles for M 2048 x N 1280 (one per CU, each streaming a 96-row weight tile:
+//                  the 32x32-latent convs lose nothing on cold weights with it, 7-9 % with 128x128)
 //   51             gemm3_kernel  128x128, 3 stages, 8 waves
 //   61 / 62        gemm3_kernel  256x256 x 2 stages / 256x128 x 3 stages, 8 waves
 //   + 1000 / + 2000  force the tile order (n-tiles / m-tiles fastest); plain codes estimate it
@@ -445,7 +447,7 @@ struct TileDim { int code, bm, bn; };
 constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {42, 128, 64}, {43, 64, 64},
                               {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256},
                               {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
-                              {52, 128, 128}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}};
+                              {52, 128, 128}, {47, 128, 96}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}};
 
 // Heuristic tile code for a shape (the default; the autotuner below and the debug hooks can replace it).
 template <int MODE>
@@ -536,6 +538,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok) {
         case 61: launch_ring<256, 256, 2, M3, 8>(ctx, a, grid); break;
         case 62: launch_ring<256, 128, 3, M3, 8>(ctx, a, grid); break;
         case 52: launch_ring<128, 128, 2, M3, 8>(ctx, a, grid); break;
+        case 47: launch_ring<128, 96, 3, M3, 4>(ctx, a, grid); break;
         case 54: launch_ring<192, 128, 2, M3, 8>(ctx, a, grid); break;
         case 46: launch_ring<64, 64, 2, M3, 4>(ctx, a, grid); break;
         case 44: launch_ring<128, 64, 2, M3, 4>(ctx, a, grid); break;
@@ -565,7 +568,8 @@ constexpr size_t kFlushBytes = 384u << 20;
 
 template <int MODE>
 int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
-    static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81};
+    static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81, 47};          // 47 (128x96): FIE_TUNE_47=0 leaves it out
+    static const bool use47 = !(getenv("FIE_TUNE_47") && getenv("FIE_TUNE_47")[0] == '0');
     static const int kW8[] = {43, 42, 62, 52, 54};
     const size_t bytes = (size_t)a.M * (a.oscat ? 4 : 1) * (size_t)a.ldc * sizeof(half_t);     // a parity conv scatters its M rows over 4 M output rows
     if (bytes > ctx->tune_bytes) {
@@ -603,7 +607,7 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     int best = guess;
     float t_best = t_guess * 0.97f;                          // a challenger has to win by 3 %
     const int* cand = a.w_scale ? kW8 : kRing;
-    const int ncand = a.w_scale ? 5 : 9;
+    const int ncand = a.w_scale ? 5 : use47 ? 10 : 9;
     for (int i = 0; i < ncand; ++i) {
         const int c = cand[i];
         if (c == guess) continue;
@@ -695,6 +699,7 @@ hipError_t ring_attrs() {
     if (e == hipSuccess) e = ring_attr<256, 256, 2, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<256, 128, 3, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<128, 128, 2, MODE, 8>();
+    if (e == hipSuccess) e = ring_attr<128, 96, 3, MODE, 4>();
     if (e == hipSuccess) e = ring_attr<192, 128, 2, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<64, 64, 2, MODE, 4>();
     if (e == hipSuccess) e = ring_attr<128, 64, 2, MODE, 4>();

@@ -240,7 +240,7 @@ def test_clip_embed(fie):
     assert rel_err(out, ref) < 2e-3
 
 
-@pytest.mark.parametrize("code", [1, 2, 3, 42, 43, 44, 46, 51, 52, 54, 61, 62, 81, 82, 95, 96, 1042, 2042, 1062, 2081])
+@pytest.mark.parametrize("code", [1, 2, 3, 42, 43, 44, 46, 47, 51, 52, 54, 61, 62, 81, 82, 95, 96, 1042, 2042, 1062, 2081])
 def test_gemm_conv_every_shipped_kernel(fie, code):
     """Every kernel / tile the launch table can select (gemm_conv.hip kTiles; + 2000 = m-tiles-fastest order) gives the
     reference result on GEMMs with ragged M / N / K tails and on convs with stride 2, asymmetric pad and fused upsample; a
