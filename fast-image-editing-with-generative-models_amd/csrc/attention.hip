@@ -488,6 +488,7 @@ extern "C" int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const
     a.Q = (const half_t*)Q; a.ldq = ldq; a.K = (const half_t*)K; a.ldk = ldk; a.V = (const half_t*)V; a.ldv = ldv;
     a.O = (half_t*)O; a.ldo = ldo; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
     a.scale_log2 = scale * 1.4426950408889634f;
+    FIE_DESC(ctx, "attn B=%d H=%d Tq=%d Tk=%d D=%d flop=%.0f", B, H, Tq, Tk, D, 4.0 * B * H * Tq * Tk * D);
     const int64_t blocks128 = (int64_t)((Tq + 127) / 128) * H * B;
     if (g_attn_variant == 1) {
         if (D == 512) return launch_attn<512, 1, 32>(ctx, a, B);

@@ -17,9 +17,46 @@ void fie_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+void fie_oplog_append(fie_ctx* ctx, const void* fn, dim3 grid, dim3 block, unsigned lds) {
+    const char* name = hipKernelNameRefByPtr(fn, ctx->stream);
+    char line[512];
+    snprintf(line, sizeof(line), "%s|%u|%u|%u|%s", name ? name : "?", grid.x * grid.y * grid.z, block.x * block.y * block.z, lds, ctx->op_desc);
+    ctx->oplog->push_back(line);
+    ctx->op_desc[0] = 0;
+}
+
 extern "C" {
 
 int fie_version(void) { return 100; }
+
+// Launch log for the per-shape profile (tools/shape_profile.py): while on, every launch of the library appends
+// "kernel symbol|blocks|threads|dynamic LDS|description" (GEMM / conv / attention / norm ops describe their problem: shape, tile code,
+// algorithmic FLOPs or bytes).  fie_debug_oplog_read copies the newline-joined log and returns its length (call with cap 0 to size).
+int fie_debug_oplog(fie_ctx* ctx, int on) {
+    FIE_REQUIRE(ctx != nullptr, "fie_debug_oplog: ctx is NULL");
+    delete ctx->oplog;
+    ctx->oplog = on ? new std::vector<std::string>() : nullptr;
+    ctx->op_desc[0] = 0;
+    return FIE_OK;
+}
+
+int fie_debug_oplog_mark(fie_ctx* ctx, const char* text) {      // a "#text" line between launches (stage boundaries)
+    FIE_REQUIRE(ctx && text, "fie_debug_oplog_mark: NULL argument");
+    if (ctx->oplog) ctx->oplog->push_back(std::string("#") + text);
+    return FIE_OK;
+}
+
+int64_t fie_debug_oplog_read(fie_ctx* ctx, char* buf, int64_t cap) {
+    if (!ctx || !ctx->oplog) return 0;
+    int64_t n = 0;
+    for (const std::string& l : *ctx->oplog) n += (int64_t)l.size() + 1;
+    if (buf && cap > n) {
+        char* q = buf;
+        for (const std::string& l : *ctx->oplog) { memcpy(q, l.data(), l.size()); q += l.size(); *q++ = '\n'; }
+        *q = 0;
+    }
+    return n;
+}
 
 const char* fie_last_error(void) { return g_err; }
 
@@ -131,6 +168,7 @@ int fie_ctx_set_stream(fie_ctx* ctx, void* stream) {
 int fie_ctx_destroy(fie_ctx* ctx) {
     if (ctx && ctx->tune_buf) (void)hipFree(ctx->tune_buf);
     if (ctx && ctx->tune_flush) (void)hipFree(ctx->tune_flush);
+    if (ctx) delete ctx->oplog;
     delete ctx;                       // registered programs are owned by the caller (fie_program_destroy)
     return FIE_OK;
 }

@@ -55,6 +55,9 @@ struct fie_ctx {
     int64_t gn_target_rows = 0;
     int gn_target_groups = 0;
     int gn_onepass = 1;                      // fie_debug_gn_onepass: 0 = always the three-kernel GroupNorm
+    void* sk_ws = nullptr;                   // fie_splitk_workspace: [4096 arrival counters (zero between launches)][fp32 partial-tile slabs]
+    int64_t sk_bytes = 0;
+    int splitk_mode = 1;                     // fie_debug_splitk: 0 = never split K, 1 = where the tuner / an override says so
     int autotune = 0;                        // fie_gemm_autotune: time the eligible tiles at a shape's first eager launch
     std::map<fie_tune_key, int> tuned;
     void* tune_buf = nullptr;                // scratch output of the timing launches
@@ -62,8 +65,10 @@ struct fie_ctx {
     size_t tune_bytes = 0;
     int n_overrides = 0;
     fie_tile_override overrides[32];
-    char last_kernel[96] = "";
+    char last_kernel[128] = "";
     fie_program* recording = nullptr;                 // launches are appended here while set (fie_program_begin / _end)
+    std::vector<std::string>* oplog = nullptr;        // fie_debug_oplog: one line per launch (kernel symbol, grid, block, LDS, the op's own description)
+    char op_desc[192] = "";                           // FIE_DESC: description of the op whose next launch is logged (consumed by that launch)
     std::map<std::string, fie_program*> graphs;       // fie_graph_register: "unet_forward", "vae_decode", ...
 };
 
@@ -75,12 +80,20 @@ inline void fie_pack_arg(fie_launch_rec& r, const T& v) {
     r.offs.push_back((unsigned)off);
 }
 
+// fie_debug_oplog (tools/shape_profile.py pairs the lines with a rocprofv3 kernel trace): ops describe themselves only while a log is open
+void fie_oplog_append(fie_ctx* ctx, const void* fn, dim3 grid, dim3 block, unsigned lds);
+#define FIE_DESC(ctx, ...)                                                              \
+    do {                                                                                \
+        if ((ctx)->oplog) snprintf((ctx)->op_desc, sizeof((ctx)->op_desc), __VA_ARGS__); \
+    } while (0)
+
 // The one launch point of the library: asynchronous on the ctx stream; recorded when a program is open.
 template <typename... KArgs, typename... Args>
 inline void fie_launch(fie_ctx* ctx, void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, Args&&... args) {
     static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count");
     std::tuple<KArgs...> vals(static_cast<KArgs>(args)...);
     std::apply([&](const KArgs&... a) { hipLaunchKernelGGL(kernel, grid, block, lds, ctx->stream, a...); }, vals);
+    if (ctx->oplog) fie_oplog_append(ctx, reinterpret_cast<const void*>(kernel), grid, block, lds);
     if (ctx->recording) {
         fie_launch_rec r;
         r.fn = reinterpret_cast<const void*>(kernel);

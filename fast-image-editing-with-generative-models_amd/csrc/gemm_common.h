@@ -41,6 +41,10 @@ struct GemmArgs {
     const float* w_scale;                   // fp8 weights (gemm_w8.hip): per-output-channel dequantisation scale [N], applied to the accumulator first; Wt then points at e4m3 bytes and ldw counts bytes
     unsigned* stamps;                       // tile codes 97 / 98: [tile][wave][8] cycle sums of the K-loop segments (fie_debug_gemm_stamps), else NULL
     int probe;                              // timing-only probes (fie_debug_gemm_probe; outputs are wrong): 1 = every DMA load dropped (zero-record descriptors), 2 = every tile fetches tile (0,0)'s operands (all L2 hits), 3 = ring kernels issue no DMA inside the K loop (MFMA + ds_read + barrier floor), 4 = no epilogue (nothing stored)
+    // split-K (ring kernels, fie_splitk_workspace): the K-steps of a tile are dealt to `splitk` consecutive blocks (one XCD under the remap); each
+    // writes its fp32 partial tile to sk_slabs[tile][slice] (write-through), draws a ticket from sk_tickets[tile]; the block that draws the last
+    // ticket sums the slices IN SLICE ORDER (deterministic) and runs the epilogue.  splitk <= 1: off
+    int splitk; float* sk_slabs; unsigned* sk_tickets;
     int order;                              // 0: n-tiles fastest (an XCD owns a range of rows), 1: m-tiles fastest (an XCD owns a range of columns)
 };
 
@@ -274,6 +278,57 @@ template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// ---- in-launch split-K reduction (guide: "Projection GEMM at M = 256" item 2, the write-through form).  Every slice block stores its
+// accumulators as whole 16-byte lane vectors ([fragment][thread]: 1 KiB per wave instruction) with sc1 (write-through) stores, every wave
+// drains its stores, the workgroup meets at a barrier and ONE lane adds to the tile's arrival counter (relaxed, agent scope).  Nobody
+// ever waits for another block (no residency assumption, no deadlock with other streams' kernels on the chip): the block whose add
+// returns splitk - 1 is the reducer.  It resets the counter for the next launch (counters start zeroed: fie_splitk_workspace), makes
+// one agent-scope acquire and reads ALL slices (its own included: no per-slice branch) in slice order with sc1 loads, so the sum
+// does not depend on which block came last.  Returns true in the reducer, whose accumulators then hold the full sums.
+template <int FM, int FN, int NW>
+__device__ __forceinline__ bool splitk_reduce(const GemmArgs& p, f32x4 (&acc)[FN][FM], int tile, int slice, int tid, void* lds) {
+    constexpr int kTile = FM * FN * NW * 64 * 4;                  // floats per slab = BM * BN
+    const int S = p.splitk;
+    float* base = p.sk_slabs + (size_t)tile * S * kTile;
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + (size_t)slice * kTile, 0, kTile * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, (unsigned)((i * FM + j) * NW * 64 + tid) * 16u, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // EVERY storing wave drains before the workgroup signals
+    __syncthreads();
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(lds);   // the ring is drained: reuse its first word (one LDS object only)
+    if (tid == 0) *flag = __hip_atomic_fetch_add(p.sk_tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != (unsigned)(S - 1)) return false;
+    if (tid == 0) {
+        __hip_atomic_store(p.sk_tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + (size_t)s * kTile, 0, kTile * 4, 0x00020000);
+        u32x4 v[FN][FM];
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) v[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((i * FM + j) * NW * 64 + tid) * 16u, 0, 16);
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] += __builtin_bit_cast(f32x4, v[i][j]);
+    }
+    return true;
 }
 
 // XCD-aware bijective tile remap: consecutive tile ids run on one XCD (blocks b and b + 8 share an XCD's L2)

@@ -182,7 +182,11 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
 
-    const int bid = take_parity(p, xcd_remap(blockIdx.x, gridDim.x));
+    // split-K: consecutive (remapped) block ids = the slices of one tile, so they share an XCD's L2 for the tile's operands and slabs
+    const int bid_all = xcd_remap(blockIdx.x, gridDim.x);
+    const int nsplit = p.splitk > 1 ? p.splitk : 1;
+    const int tile_all = bid_all / nsplit, slice = bid_all - tile_all * nsplit;
+    const int bid = take_parity(p, tile_all);
     const int m0 = (p.order ? bid % p.nbm : bid / p.nbn) * BM;
     const int n0 = (p.order ? bid / p.nbm : bid % p.nbn) * BN;
     const int lr = lane >> 3;
@@ -227,11 +231,14 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < RW; ++i) w_off[i] = (unsigned)(ln0 + (wave + NW * i) * 8 + lr) * (unsigned)p.ldw * 2u + c8 * 16u;
 
-    int cs = 0, ftap = 0;
     const int csteps = MODE == 2 ? p.Cin / BK : 1;
     const int k1_steps = p.K1 / BK;            // GEMM: K-steps served by A1 (K1 % 64 == 0 unless K1 == K)
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kbeg = (int)((int64_t)nk_all * slice / nsplit);          // this block's K-steps: [kbeg, kbeg + nk); all of them without split-K
+    const int nk = (int)((int64_t)nk_all * (slice + 1) / nsplit) - kbeg;
     const bool ktail = (p.K % BK) != 0;
+    int ftap = kbeg / csteps, cs = kbeg - ftap * csteps;              // conv: tap and channel step of the next K-step to issue
+    bool tap_fresh = true;                                            // a slice may start in the middle of a tap
 
     const int ntaps = p.taps2 ? 4 : 9;
     auto issue = [&](int kt, int stage) {
@@ -246,7 +253,8 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
                 for (int i = 0; i < RA; ++i) bload16(rs_a3, sa + (wave + NW * i) * 512, a_off3[i], (unsigned)(e - x2) * (BK * 2));
             }
         } else if (MODE == 2) {
-            if (cs == 0) {
+            if (cs == 0 || tap_fresh) {
+                tap_fresh = false;
                 const int ky = p.taps2 ? ftap >> 1 : (ftap * 11) >> 5, kx = p.taps2 ? ftap & 1 : ftap - 3 * ky;
                 const int hlim = p.H << p.ups, wlim = p.W << p.ups;
 #pragma unroll
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, a_off1[i], so);
             if (++cs == csteps) { cs = 0; ++ftap; }
         } else {
-            if (ktail && kt == nk - 1) {               // last, partial K-step: columns >= K read as zero
+            if (ktail && kt == nk_all - 1) {           // last, partial K-step: columns >= K read as zero
                 const bool in_k = kt * BK + c8 * 8 < p.K;
 #pragma unroll
                 for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, in_k ? a_off1[i] : kOob, (unsigned)kt * (BK * 2));
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
 
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
-        if (s < nk) { issue(s, s); issue_w(s, s); }
+        if (s < nk) { issue(kbeg + s, s); issue_w(kbeg + s, s); }
 
     const int fr = lane & 15, fq = lane >> 4;
     int stage = 0, fill = ST - 1;
@@ -352,12 +360,12 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         for (int kt = 0; kt < nk; ++kt) {
             stamp(kt == 0 ? 7 : 0);                        // whole K-steps only: a stamp drains lgkmcnt
             const bool more = kt + ST - 1 < nk && p.probe != 3;
-            if (more) { issue(kt + ST - 1, fill); if (NW != 8) issue_w(kt + ST - 1, fill); }
+            if (more) { issue(kbeg + kt + ST - 1, fill); if (NW != 8) issue_w(kbeg + kt + ST - 1, fill); }
             reads(fw1, fa1, stage, 1);
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
             landed(fw0, fa0);
             mfmas(fw0, fa0);
-            if (more && NW == 8) issue_w(kt + ST - 1, fill);
+            if (more && NW == 8) issue_w(kbeg + kt + ST - 1, fill);
             stage = stage + 1 == ST ? 0 : stage + 1;
             fill = fill + 1 == ST ? 0 : fill + 1;
             // every read of the stage consumed in this K-step has returned before any wave may refill it (next iteration)
@@ -382,8 +390,8 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             // spends a whole K-step's worth of LDS-DMA issue slots before its first MFMA
             // (measured: pays for the 8-wave blocks, costs 10 % on the 4-wave ones, which keep one burst per K-step)
             if (more && p.probe != 3) {                // probe 3: no DMA issued inside the K loop at all (stale LDS data)
-                if (kk == 0) { issue(kt + ST - 1, fill); if (NW != 8) issue_w(kt + ST - 1, fill); }
-                else if (NW == 8) issue_w(kt + ST - 1, fill);
+                if (kk == 0) { issue(kbeg + kt + ST - 1, fill); if (NW != 8) issue_w(kbeg + kt + ST - 1, fill); }
+                else if (NW == 8) issue_w(kbeg + kt + ST - 1, fill);
             }
             stamp(1 + 3 * kk);                             // 1 / 4: DMA issue
             f16x8 fw[FN], fa[FM];
@@ -397,6 +405,9 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         fill = fill + 1 == ST ? 0 : fill + 1;
     }
     stamp(11);                                             // last MFMA group issued
+    if constexpr (FM * FN <= 16) {                         // split-K: only the block that draws the tile's last ticket goes on, with the summed slices
+        if (nsplit > 1 && !splitk_reduce<FM, FN, NW>(p, acc, tile_all, slice, tid, smem)) return;
+    }
     if constexpr (FM * FN > 16) {                          // 256x256: two column halves, see gemm8.hip
         static_assert(FN == 4, "");
         epilogue<FM, 2, WM, WN, true>(p, reinterpret_cast<f32x4(&)[2][FM]>(acc[0]), m0, n0, wm, wn, lane);
@@ -485,8 +496,22 @@ int heuristic_code(const fie_ctx* ctx, const GemmArgs& a, bool dma_ok) {
 }
 
 // One launch of `code` (order: 0 n-tiles fastest, 1 m-tiles fastest, -1 estimate).
+constexpr int64_t kSkTickets = 4096;        // arrival counters at the head of the split-K workspace
+
+// Largest usable split for a tile code: ring kernels with <= 16 accumulator fragments per lane (not 256x256), at least 4 K-steps per
+// slice, counters and slabs inside the bound workspace.  Returns 1 when split-K cannot run.
+inline int splitk_fit(const fie_ctx* ctx, const GemmArgs& a, int code, int bm, int bn, int want) {
+    const bool ring = (code >= 42 && code <= 54) || code == 62 || code == 95 || code == 96;
+    if (want <= 1 || !ring || !ctx->sk_ws || !ctx->splitk_mode || a.w_scale) return 1;
+    const int64_t tiles = (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (a.oscat == 2 ? 4 : 1);
+    const int nk = (a.K + BK - 1) / BK;
+    int s = want;
+    while (s > 1 && (nk / s < 4 || tiles > kSkTickets || (int64_t)(kSkTickets * 4 + tiles * s * bm * bn * 4) > ctx->sk_bytes)) --s;
+    return s;
+}
+
 template <int MODE>
-int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok) {
+int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int split = 1) {
     const TileDim* t = nullptr;
     for (const TileDim& d : kTiles)
         if (d.code == code) t = &d;
@@ -517,16 +542,26 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok) {
     }
     a.nbm = (a.M + t->bm - 1) / t->bm;
     a.nbn = (a.N + t->bn - 1) / t->bn;
+    split = splitk_fit(ctx, a, code, t->bm, t->bn, split);
+    a.splitk = split;
+    a.sk_tickets = static_cast<unsigned*>(ctx->sk_ws);
+    a.sk_slabs = reinterpret_cast<float*>(static_cast<char*>(ctx->sk_ws) + kSkTickets * 4);
     a.order = order;
     a.probe = ctx->gemm_probe;
     a.stamps = (code == 97 || code == 98 || code == 94) ? ctx->gemm_stamps : nullptr;
     snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 90 ? "gemm3_kernel+prefetch" : code >= 80 ? "gemm8_kernel" : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
              t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
+    if (split > 1) snprintf(ctx->last_kernel + strlen(ctx->last_kernel) - 1, 24, ", split-K %d)", split);
+    if (MODE == 1)
+        FIE_DESC(ctx, "conv M=%d N=%d K=%d in=%dx%dx%d s%d u%d%s%s code=%d flop=%.0f", a.M * (a.oscat == 2 ? 4 : 1), a.N, a.K, a.H, a.W, a.Cin, a.stride, a.ups,
+                 a.taps2 ? " up2x-parity" : "", a.A2 ? " +1x1" : "", code + 10000 * (split > 1 ? split : 0), 2.0 * a.M * a.N * a.K * (a.oscat == 2 ? 4 : 1));
+    else
+        FIE_DESC(ctx, "gemm M=%d N=%d K=%d act=%d%s%s code=%d flop=%.0f", a.M, a.N, a.K, a.act, a.res ? " +res" : "", a.w_scale ? " w8" : "", code + 10000 * (split > 1 ? split : 0), 2.0 * a.M * a.N * a.K);
     if (a.w_scale) {
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "gemm3w8_kernel<%dx%d> (%s, fp8 weights, tile code %d)", t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
         return fie_launch_gemm_w8(ctx, a, MODE == 1, code);
     }
-    const dim3 grid((unsigned)(a.nbm * a.nbn * (a.oscat == 2 ? 4 : 1))), block(256);
+    const dim3 grid((unsigned)(a.nbm * a.nbn * (a.oscat == 2 ? 4 : 1) * split)), block(256);
     constexpr int M3 = MODE == 1 ? 2 : 0;
     switch (code) {
         case 1: fie_launch(ctx, (gemm_kernel<128, 128, MODE>), grid, block, 0, a); break;
@@ -586,14 +621,14 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     GemmArgs t = a;
     t.C = static_cast<half_t*>(ctx->tune_buf);           // a residual that aliases C is still read from the caller's buffer
     auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-    auto time_of = [&](int code) -> float {
+    auto time_of = [&](int code, int split = 1) -> float {
         float ms[7];
         for (int rep = -1; rep < 7; ++rep) {               // rep -1: untimed (first use of the kernel)
             (void)hipMemsetAsync(ctx->tune_flush, rep & 1, kFlushBytes, ctx->stream);
             if ((size_t)a.a1_bytes <= kFlushBytes) (void)hipMemcpyAsync(ctx->tune_flush, a.A1, (size_t)a.a1_bytes, hipMemcpyDeviceToDevice, ctx->stream);
             if (a.A2 && a.A2 != a.A1 && (size_t)a.a2_bytes <= kFlushBytes) (void)hipMemcpyAsync(ctx->tune_flush, a.A2, (size_t)a.a2_bytes, hipMemcpyDeviceToDevice, ctx->stream);
             (void)hipEventRecord(e0, ctx->stream);
-            if (run_code<MODE>(ctx, t, code, -1, dma_ok) != FIE_OK) return 1e30f;
+            if (run_code<MODE>(ctx, t, code, -1, dma_ok, split) != FIE_OK) return 1e30f;
             (void)hipEventRecord(e1, ctx->stream);
             if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
             if (rep >= 0) (void)hipEventElapsedTime(&ms[rep], e0, e1);
@@ -618,6 +653,23 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
         if (verbose) fprintf(stderr, ", %d %.1f", c, tc * 1e3f);
         if (tc < t_best) { t_best = tc; best = c; }
     }
+    // split-K: big tiles whose grid leaves CUs idle (the M = 2048 class: 80 tiles of 256x128 on 256 CUs) with the K-steps of a tile dealt
+    // to 2-4 blocks, reduced in the launch (gemm_common.h: splitk_reduce).  Changes the fp32 summation order, so unlike the tile choice
+    // it is visible in the last bit of some f16 outputs; fixed per (shape, choice), hence deterministic within a process.
+    if (!a.w_scale && ctx->sk_ws && ctx->splitk_mode) {
+        static const struct { int code, bm, bn, per_cu; } kSplit[] = {{96, 256, 128, 1}, {95, 128, 128, 1}, {47, 128, 96, 1}, {54, 192, 128, 2}, {52, 128, 128, 2}};
+        for (const auto& c : kSplit) {
+            const int64_t nb = blocks(c.bm, c.bn) * (a.oscat == 2 ? 4 : 1);
+            if (nb >= ctx->num_cus * c.per_cu) continue;                 // the grid already fills the chip
+            for (int sp = 2; sp <= 4; ++sp) {
+                if (nb * sp > (int64_t)ctx->num_cus * c.per_cu * 21 / 20) break;
+                if (splitk_fit(ctx, a, c.code, c.bm, c.bn, sp) != sp) continue;
+                const float tc = time_of(c.code, sp);
+                if (verbose) fprintf(stderr, ", %d/s%d %.1f", c.code, sp, tc * 1e3f);
+                if (tc < t_best) { t_best = tc; best = c.code + 10000 * sp; }
+            }
+        }
+    }
     if (verbose) fprintf(stderr, " -> %d\n", best);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -634,26 +686,29 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     FIE_REQUIRE(!(MODE == 1 && a.A2 && !dma_ok), "conv + 1x1 side inputs: tensors too large for the LDS-DMA kernels");
     int code = heuristic_code<MODE>(ctx, a, dma_ok);
     int order = -1;                // 0: n-tiles fastest (an XCD owns a range of activation rows), 1: m-tiles fastest; -1: estimate
+    int split = 1;                 // encoded choices: split-K factor * 10000 + (1000 / 2000: forced tile order) + tile code
     bool pinned = false;
+    auto decode = [&](int v) { split = v / 10000 > 1 ? v / 10000 : 1; v %= 10000; order = v >= 2000 ? 1 : v >= 1000 ? 0 : -1; code = v % 1000; };
     for (int i = 0; i < ctx->n_overrides; ++i) {
         const fie_tile_override& o = ctx->overrides[i];
-        if (o.mode == (MODE == 1) && o.M == a.M && o.N == a.N && o.K == a.K) { code = o.code % 1000; order = o.code >= 2000 ? 1 : o.code >= 1000 ? 0 : -1; pinned = true; }
+        if (o.mode == (MODE == 1) && o.M == a.M && o.N == a.N && o.K == a.K) { decode(o.code); pinned = true; }
     }
-    if (ctx->force_tile) { code = ctx->force_tile % 1000; order = ctx->force_tile >= 2000 ? 1 : ctx->force_tile >= 1000 ? 0 : -1; pinned = true; }
+    if (ctx->force_tile) { decode(ctx->force_tile); pinned = true; }
     if (ctx->autotune && !pinned && dma_ok && !ctx->gemm_probe) {      // 1: tune shapes not met before, 2: remembered shapes only
         const fie_tune_key key{MODE, a.M, a.N, a.K, a.K1, MODE == 1 ? a.stride * 2 + a.ups + 8 * a.taps2 + 16 * (a.A2 != nullptr) + 32 * (a.A3 != nullptr) : 0, a.w_scale != nullptr};
         auto it = ctx->tuned.find(key);
         if (it != ctx->tuned.end()) {
-            code = it->second;
+            decode(it->second);
         } else if (ctx->autotune == 1 && !ctx->recording) {
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
-                code = autotune<MODE>(ctx, a, code, dma_ok);
-                ctx->tuned[key] = code;
+                const int best = autotune<MODE>(ctx, a, code, dma_ok);
+                ctx->tuned[key] = best;
+                decode(best);
             }
         }
     }
-    return run_code<MODE>(ctx, a, code, order, dma_ok);
+    return run_code<MODE>(ctx, a, code, order, dma_ok, split);
 }
 
 int check_epilogue(const char* who, int N, int64_t ldc, const void* res, int64_t ldr, int act) {
@@ -758,6 +813,19 @@ int fie_gn_stats_target(fie_ctx* ctx, void* partial, int64_t rows_per_image, int
     ctx->gn_target = static_cast<float*>(partial);
     ctx->gn_target_rows = rows_per_image;
     ctx->gn_target_groups = groups;
+    return FIE_OK;
+}
+
+int fie_splitk_workspace(fie_ctx* ctx, void* ws, int64_t bytes) {
+    FIE_REQUIRE(ctx != nullptr && (ws == nullptr || bytes >= kSkTickets * 4 + (1 << 20)), "fie_splitk_workspace: bad argument (at least 1 MiB + 16 KiB)");
+    ctx->sk_ws = ws;
+    ctx->sk_bytes = ws ? bytes : 0;
+    return FIE_OK;
+}
+
+int fie_debug_splitk(fie_ctx* ctx, int mode) {
+    FIE_REQUIRE(ctx != nullptr && (mode == 0 || mode == 1), "fie_debug_splitk: bad argument");
+    ctx->splitk_mode = mode;
     return FIE_OK;
 }
 

@@ -319,6 +319,7 @@ bool gn_onepass(fie_ctx* ctx, const GnArgsT<T>& p, int B) {
     const int npv = p.cg / V, rstep = GN1_THREADS / npv;
     const int64_t nv = (p.rows + rstep - 1) / rstep;
     const dim3 grid((unsigned)p.G, (unsigned)B);
+    FIE_DESC(ctx, "groupnorm onepass B=%d rows=%lld C=%d G=%d bytes=%.0f", B, (long long)p.rows, p.C, p.G, 2.0 * B * p.rows * p.C * sizeof(T));
     if (V == 8 && nv <= 5) fie_launch(ctx, (gn_onepass_kernel<8, 5, T>), grid, dim3(GN1_THREADS), 0, p);
     else if (V == 8 && nv <= 10) fie_launch(ctx, (gn_onepass_kernel<8, 10, T>), grid, dim3(GN1_THREADS), 0, p);
     // V = 4 at rows = 4096 (64x64 latents, 21 vectors) measured SLOWER than the three-kernel path (28.5 vs 22.0 us: 40-byte
@@ -422,8 +423,11 @@ int groupnorm_t(const char* who, fie_ctx* ctx, const void* X1, int C1, const voi
     p.partial = (float*)workspace;
     p.stats = p.partial + (int64_t)B * GN_MAX_CHUNKS * groups * 2;
     const dim3 grid((unsigned)p.nchunks, (unsigned)B, (unsigned)csplit);
+    FIE_DESC(ctx, "groupnorm partial B=%d rows=%lld C=%d G=%d bytes=%.0f", B, (long long)rows_per_image, C, groups, 1.0 * B * rows_per_image * C * sizeof(T));
     fie_launch(ctx, gn_partial_kernel<T>, grid, dim3(GN_THREADS), 0, p);
+    FIE_DESC(ctx, "groupnorm finalize B=%d rows=%lld C=%d G=%d bytes=0", B, (long long)rows_per_image, C, groups);
     fie_launch(ctx, gn_finalize_kernel<T>, dim3((B * groups + 3) / 4), dim3(256), 0, p, B);
+    FIE_DESC(ctx, "groupnorm apply B=%d rows=%lld C=%d G=%d bytes=%.0f", B, (long long)rows_per_image, C, groups, 2.0 * B * rows_per_image * C * sizeof(T));
     fie_launch(ctx, gn_apply_kernel<T>, grid, dim3(GN_THREADS), 0, p);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
@@ -435,6 +439,7 @@ int layernorm_t(const char* who, fie_ctx* ctx, const void* X, int64_t ldx, void*
     FIE_REQUIRE(ctx && X && Y && gamma && beta, "%s: NULL argument", who);
     FIE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "%s: C=%d unsupported", who, C);
     FIE_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "%s: bad strides", who);
+    FIE_DESC(ctx, "layernorm rows=%lld C=%d bytes=%.0f", (long long)rows, C, 2.0 * rows * C * sizeof(T));
     fie_launch(ctx, ln_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (const T*)X, ldx, (T*)Y, ldy, rows, C, (const T*)gamma, (const T*)beta, eps);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
@@ -462,7 +467,9 @@ int groupnorm_stats_t(const char* who, fie_ctx* ctx, const void* X, int C, void*
     GnArgsT<T> f = p;                                       // finalize walks the producer's granules, apply its own row chunks
     f.partial = const_cast<float*>((const float*)partial);
     f.nchunks = (int)(rows_per_image / 32);
+    FIE_DESC(ctx, "groupnorm finalize-from-epilogue B=%d rows=%lld C=%d G=%d bytes=0", B, (long long)rows_per_image, C, groups);
     fie_launch(ctx, gn_finalize_wide_kernel<T>, dim3(B * groups), dim3(256), 0, f, B);
+    FIE_DESC(ctx, "groupnorm apply B=%d rows=%lld C=%d G=%d bytes=%.0f", B, (long long)rows_per_image, C, groups, 2.0 * B * rows_per_image * C * sizeof(T));
     fie_launch(ctx, gn_apply_kernel<T>, grid, dim3(GN_THREADS), 0, p);
     FIE_LAUNCH_CHECK();
     return FIE_OK;

@@ -85,6 +85,11 @@ SIGNATURES = {
     "fie_gemm_autotune_report": [_P, ctypes.c_char_p, _I],
     "fie_debug_gemm_probe": [_P, _I],
     "fie_debug_gemm_stamps": [_P, _P],
+    "fie_splitk_workspace": [_P, _P, _L],
+    "fie_debug_splitk": [_P, _I],
+    "fie_debug_oplog": [_P, _I],
+    "fie_debug_oplog_mark": [_P, _c.c_char_p],
+    "fie_debug_oplog_read": [_P, _c.c_char_p, _L],
 }
 
 _lib = None
@@ -110,7 +115,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.argtypes = args
-            fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes", "fie_time_embed_workspace_bytes", "fie_gn_stats_bytes") else _I
+            fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes", "fie_time_embed_workspace_bytes", "fie_gn_stats_bytes", "fie_debug_oplog_read") else _I
         _lib.fie_last_error.restype = ctypes.c_char_p
         _lib.fie_last_error.argtypes = []
         _lib.fie_debug_last_gemm_kernel.restype = ctypes.c_char_p
@@ -197,6 +202,9 @@ class Context:
         self._gn_ws = {}
         self._gn_stats = {}
         self._gn_gen = 0
+        self._sk_ws = {}               # split-K workspaces (fie_splitk_workspace), one per (stream, graph slot)
+        self._sk_bound = None
+        self.splitk_bytes = int(os.environ.get("FIE_SPLITK_MB", "96")) << 20      # 0: never split K
         self.gn_from_epilogue = os.environ.get("FIE_GN_FROM_EPILOGUE", "1") != "0"
         self.up2x_parity = os.environ.get("FIE_UP2X_PARITY", "1") != "0"
         self.conv_plus_shortcut = os.environ.get("FIE_CONV_PLUS", "1") != "0"   # resnet conv2 + 1x1 shortcut as one GEMM (fie_conv3x3_plus_nhwc_f16)      # 2x-upsampling convs as four 2x2 convs (fie_conv_up2x_nhwc_f16)
@@ -210,6 +218,20 @@ class Context:
         if s != self._stream:
             _chk(lib().fie_ctx_set_stream(self.h, s))
             self._stream = s
+
+    def _bind_splitk(self):
+        """Split-K launches that may run concurrently must not share arrival counters / slabs: every (stream, graph slot) owns a
+        workspace (zeroed once: the kernels leave the counters zero), bound to the C context before a GEMM / conv is issued there."""
+        key = (self._stream, self.ws_tag)
+        if key == self._sk_bound or self.f32 or not self.splitk_bytes:
+            return
+        ws = self._sk_ws.get(key)
+        if ws is None:
+            ws = self._sk_ws[key] = torch.zeros(self.splitk_bytes, device=self.device, dtype=torch.uint8)
+        if self._keep is not None:
+            self._keep.append(ws)
+        _chk(lib().fie_splitk_workspace(self.h, ws.data_ptr(), ws.numel()))
+        self._sk_bound = key
 
     # ------------------------------------------------------------------ launch programs / graph-level entries
     def record(self):
@@ -259,6 +281,25 @@ class Context:
         buf = ctypes.create_string_buffer(1 << 16)
         n = lib().fie_gemm_autotune_report(self.h, buf, len(buf))
         return n, buf.value.decode()
+
+    def splitk(self, on=True):
+        """False: no launch of this context splits K (A/B switch; the tuner's remembered split choices fall back to the unsplit tile)."""
+        _chk(lib().fie_debug_splitk(self.h, int(bool(on))))
+
+    def oplog(self, on=True):
+        """Launch log (include/fie.h: fie_debug_oplog): one line per kernel launch with the op's shape description."""
+        _chk(lib().fie_debug_oplog(self.h, int(on)))
+        self._oplog_on = bool(on)
+
+    def oplog_mark(self, text):
+        if getattr(self, "_oplog_on", False):
+            _chk(lib().fie_debug_oplog_mark(self.h, text.encode()))
+
+    def oplog_read(self):
+        n = lib().fie_debug_oplog_read(self.h, None, 0)
+        buf = ctypes.create_string_buffer(int(n) + 16)
+        lib().fie_debug_oplog_read(self.h, buf, len(buf))
+        return [l for l in buf.value.decode().split("\n") if l]
 
     def gemm_stamps(self, buf):
         """Device int32 tensor [tiles * waves * 8] the stamped ring kernels (tile codes 97 / 98) write their cycle sums to; None detaches."""
@@ -347,6 +388,7 @@ class Context:
              act=ACT_NONE, k=None, gn_stats=None):
         """a: [M, K1] (last-dim contiguous, row stride free), optional a2: [M, K2]; wp packed weight; n logical N."""
         self.sync_stream()
+        self._bind_splitk()
         m, k1 = a.shape
         ktot = k1 + (a2.shape[1] if a2 is not None else 0)
         if k is not None:
@@ -378,6 +420,7 @@ class Context:
     def conv3x3_plus(self, x, wp, cout, x2, x3=None, bias=None, rowbias=None, scale=1.0, act=ACT_NONE, gn_groups=None):
         """conv3x3(x) + [x2 | x3] @ W1x1^T in one GEMM (include/fie.h: fie_conv3x3_plus_nhwc_f16); x2 / x3: [B*H*W, C] views, last dim contiguous."""
         self.sync_stream()
+        self._bind_splitk()
         b, h, w, cin = x.shape
         assert x.is_contiguous() and not self.f32 and x2.stride(1) == 1 and (x3 is None or x3.stride(1) == 1)
         out = self._alloc((b, h, w, cout))
@@ -403,6 +446,7 @@ class Context:
     def conv_up2x(self, x, wp4, cout, bias=None, rowbias=None, scale=1.0, act=ACT_NONE, gn_groups=None):
         """conv3x3(nearest-2x(x)) from the four parity matrices of pack_conv_up2x: x [B, H, W, Cin] -> [B, 2H, 2W, cout]."""
         self.sync_stream()
+        self._bind_splitk()
         b, h, w, cin = x.shape
         assert x.is_contiguous() and not self.f32 and cin % 64 == 0
         out = self._alloc((b, 2 * h, 2 * w, cout))
@@ -416,6 +460,7 @@ class Context:
                 residual=None, scale=1.0, act=ACT_NONE, ldc=None, gn_groups=None):
         """x: [B, H, W, Cin] f16 contiguous NHWC -> [B, OH, OW, ldc]."""
         self.sync_stream()
+        self._bind_splitk()
         b, h, w, cin = x.shape
         assert x.is_contiguous()
         hin, win = (h * 2, w * 2) if upsample else (h, w)

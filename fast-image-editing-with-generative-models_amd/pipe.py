@@ -185,6 +185,7 @@ class HipImg2ImgPipeline:
         return self._side
 
     def _mark(self, name):
+        self.ctx.oplog_mark(name)
         if self.timing is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()

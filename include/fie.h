@@ -267,11 +267,22 @@ int fie_groupnorm_stats_nhwc_f16(fie_ctx* ctx, const void* X, int C, void* Y, in
 /* Touches one dword of every 128-byte line of [ptr, ptr + bytes) with `blocks` small workgroups on `stream` (NULL: the context's): pulls a
  * weight matrix from HBM into the Infinity Cache ahead of the kernel that will stream it.  Reads only; no result. */
 int fie_prefetch(fie_ctx* ctx, const void* ptr, int64_t bytes, void* stream, int blocks);
+/* Split-K for the GEMM / conv ring kernels (M = 2048-class problems whose big tiles leave most CUs idle): binds a caller-owned device
+ * workspace to the context -- 16 KiB of arrival counters that MUST be zero when bound (every launch leaves them zero again) followed by
+ * the fp32 partial-tile slabs.  Launches that run concurrently (different streams) need different workspaces: bind the stream's own
+ * before issuing on it.  NULL unbinds (no launch splits K then).  A launch splits only where the autotuner measured it faster, or an
+ * override asks (tile codes: split factor * 10000 + code); it falls back to the unsplit kernel when the workspace is too small.
+ * Determinism: slices are summed in slice order by the block that arrives last, so results do not depend on timing. */
+int fie_splitk_workspace(fie_ctx* ctx, void* workspace, int64_t bytes);
+int fie_debug_splitk(fie_ctx* ctx, int mode);                       /* 0 = never split K, 1 = default */
 int fie_gemm_autotune(fie_ctx* ctx, int on);
 int fie_gemm_autotune_report(fie_ctx* ctx, char* buf, int cap);
 int fie_debug_gemm_probe(fie_ctx* ctx, int mode);                  /* TIMING-ONLY probes of the LDS-DMA kernels (outputs are wrong): 0 off, 1 = DMA loads dropped by the descriptor, 2 = every tile loads tile (0,0), 3 = ring kernels: no DMA issued in the K loop, 4 = no epilogue */
 int fie_debug_gemm_stamps(fie_ctx* ctx, void* buf);                  /* device buffer for the stamped ring kernels (tile codes 97 / 98): per tile and wave 8 uint32 cycle sums -- [0] drain + barrier, [1]/[4] DMA issue, [2]/[5] fragment reads, [3]/[6] MFMA issue (code 98: [0] = whole K-steps); NULL detaches */
 const char* fie_debug_last_gemm_kernel(fie_ctx* ctx);              /* kernel / tile of the last fie_gemm_f16 / fie_conv3x3_nhwc_f16 launch */
+int fie_debug_oplog(fie_ctx* ctx, int on);                         /* launch log for the per-shape profile (tools/shape_profile.py): while on, every launch appends "kernel symbol|blocks|threads|LDS bytes|op description (shape, tile code, algorithmic flop / bytes)" */
+int fie_debug_oplog_mark(fie_ctx* ctx, const char* text);           /* appends "#text" (a stage boundary) when the log is on */
+int64_t fie_debug_oplog_read(fie_ctx* ctx, char* buf, int64_t cap);  /* newline-joined log into buf when it fits; returns its length (cap 0: size query) */
 int fie_debug_attn_variant(int variant);   /* 0 = default kernel, 1 = first-generation kernel (A/B benchmarking) */
 int fie_debug_gn_onepass(fie_ctx* ctx, int enable);      /* per context; 1 = default (single-pass GroupNorm on small maps), 0 = always partial/finalize/apply */
 

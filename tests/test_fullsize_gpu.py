@@ -129,32 +129,156 @@ def test_lcm_step_identity_full_size(fie):
     assert torch.allclose(lat, ref / 0.5, rtol=1e-6)
 
 
-def test_full_size_fp16_vs_fp32_paths(big, fie):
-    """north_star tolerance at BASELINE size: the fp16 hot path against the exact-fp32 HIP path (same seeded weights, fp32
-    noise from a CPU generator, SSD-1B-A' + ControlNet-full, 1024x1024, 2 evals, CFG): SSIM >= 0.99 at the metric
-    resolution (512x512 LANCZOS, reference src/metrics.py:227-231) and at full resolution."""
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE-size composites against the CPU oracle (oracle/nets.py, oracle/pipeline.py) -- VERDICT r02 "missing #2": the
+# north_star gate (SSIM >= 0.99 vs the reference output of /root/reference/src/pipeline.py:212-274) used to be asserted
+# against the oracle on the tiny stacks only.  Same seeded weights on both sides (fp16-rounded), fp32 noise from a CPU
+# generator.  Oracle cost on the GPU box's 16 host cores: ~8 s per batch-1 ControlNet + UNet evaluation, ~5 s VAE encode,
+# ~10 s VAE decode, ~45 s for the whole edit (2 evaluations at CFG batch 2).
+# Tolerances: fp16 storage + fp32 accumulation against the fp32 oracle: per-tensor max-abs error relative to the tensor's
+# max-abs <= 2e-2 for the deep composites (the bar of tests/test_pipeline_gpu.py on the tiny stacks); image: SSIM >= 0.99.
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+@pytest.fixture(scope="module")
+def full(fie):
+    """SSD-1B-A' + ControlNet-full + VAE + CLIPs: ONE set of seeded weights, as fp32 dicts for the oracle (values fp16-rounded)
+    and packed into the fp16 HIP pipeline."""
+    from fie_amd import stack
+    from fie_amd.pipe import HipImg2ImgPipeline
+    cfgs, sds = stack.synthetic_stack("ssd-1b", True, device="cpu", dtype=torch.float16)
+    pipe = HipImg2ImgPipeline(fie, cfgs, sds, noise_dtype=torch.float32)
+    sds32 = {k: {n: v.float() for n, v in sd.items()} for k, sd in sds.items()}
+    del sds
+    return cfgs, sds32, pipe
+
+
+def test_full_size_unet_controlnet_eval_vs_oracle(full, fie):
+    """One ControlNet + UNet evaluation at 128x128 latents / a 1024x1024 edge map, batch 1, t = 499, conditioning scale 0.5."""
+    from oracle import nets
+    cfgs, sds32, pipe = full
+    g = torch.Generator().manual_seed(5)
+    lh = lw = 128
+    lat = torch.randn(1, 4, lh, lw, generator=g).half().float()
+    cond = (torch.rand(1, 3, lh * 8, lw * 8, generator=g) > 0.9).float()
+    xd = cfgs["unet"]["cross_attention_dim"]
+    text = torch.randn(1, 77, xd, generator=g).half().float()
+    pooled = torch.randn(1, 1280, generator=g).half().float()
+    tid = torch.tensor([[1024., 1024., 0, 0, 1024., 1024.]])
+    t = 499
+    with torch.no_grad():
+        down, mid = nets.controlnet_forward(sds32["controlnet"], cfgs["controlnet"], lat, t, text, cond, 0.5, pooled, tid)
+        ref = nets.unet_forward(sds32["unet"], cfgs["unet"], lat, t, text, pooled, tid, down, mid)
+    dev = fie.device
+    model_in = torch.zeros(1, lh, lw, 8, dtype=torch.float16, device=dev)
+    model_in[..., :4] = lat.permute(0, 2, 3, 1).half().to(dev)
+    cond8 = torch.zeros(1, lh * 8, lw * 8, 8, dtype=torch.float16, device=dev)
+    cond8[..., :3] = cond.permute(0, 2, 3, 1).half().to(dev)
+    text_d = text.reshape(77, xd).half().to(dev)
+    pipe.unet.begin_image(pooled.half().to(dev), tid.to(dev))
+    pipe.controlnet.begin_image(pooled.half().to(dev), tid.to(dev))
+    cemb = pipe.controlnet.cond_embedding(cond8)
+    t_dev = torch.full((1, 1), float(t), device=dev)
+    tb_u, tb_c = pipe.unet.time_rowbias(t_dev), pipe.controlnet.time_rowbias(t_dev)
+    skips, m = pipe.unet.encode(pipe.unet.conv_in(fie, model_in), tb_u, text_d, 77)
+    c_skips, c_mid = pipe.controlnet.encode_cond(model_in, cemb, tb_c, text_d, 77)
+    # the ControlNet residuals themselves (before they disappear into the UNet's skip tensors)
+    zero = [torch.zeros_like(s) for s in skips]
+    r_skips, r_mid = pipe.controlnet.add_residuals(c_skips, c_mid, 0.5, zero, torch.zeros_like(m))
+    worst = max(rel_err(a.permute(0, 3, 1, 2), b) for a, b in zip(r_skips + [r_mid], list(down) + [mid]))
+    skips2, m2 = pipe.controlnet.add_residuals(c_skips, c_mid, 0.5, skips, m)
+    eps = pipe.unet.decode(m2, skips2, tb_u, text_d, 77)
+    e = rel_err(eps.permute(0, 3, 1, 2), ref)
+    print(f"full-size eval vs oracle: eps rel_err={e:.2e}, worst ControlNet residual rel_err={worst:.2e}")
+    assert worst < 2e-2 and e < 2e-2
+
+
+def test_full_size_vae_encode_decode_vs_oracle(full, fie):
+    """VAE encoder moments of a 1024x1024 image and decoder output of a 128x128 latent against the oracle."""
+    from oracle import nets, pipeline as opipe
+    from test_pipeline_gpu import synth_image
+    cfgs, sds32, pipe = full
+    img = synth_image(3, 1024)
+    x = opipe.pil_to_float(img, True)
+    with torch.no_grad():
+        mean, logvar = nets.vae_encode_moments(sds32["vae"], cfgs["vae"], x)
+    u8 = torch.from_numpy(np.array(img)).cuda()
+    mom, (lh, lw) = pipe.vae.encode_moments(fie.pixels_in(u8, True))
+    assert (lh, lw) == (128, 128)
+    ref = torch.cat([mean, logvar], 1)[0].permute(1, 2, 0).reshape(lh * lw, 8)
+    e_enc = rel_err(mom, ref)
+    z = torch.zeros(1, lh, lw, 8, dtype=torch.float16)
+    z[..., :4] = mean[0].permute(1, 2, 0).half()
+    dec = pipe.vae.decode(z.cuda())
+    with torch.no_grad():
+        ref_dec = nets.vae_decode(sds32["vae"], cfgs["vae"], mean.half().float())
+    e_dec = rel_err(dec[0, ..., :3].permute(2, 0, 1), ref_dec[0])
+    print(f"full-size VAE vs oracle: moments rel_err={e_enc:.2e}, decode rel_err={e_dec:.2e}")
+    assert e_enc < 2e-2 and e_dec < 2e-2
+
+
+_EDIT_KW = dict(strength=0.5, num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5)
+_PROMPT = "a slanted [rusty] mountain bicycle on the road in front of a building"
+
+
+@pytest.fixture(scope="module")
+def oracle_edit(full):
+    """oracle.pipeline.run on BASELINE configs[1]: 1024x1024, strength 0.5 (2 evaluations), guidance 1.5 (CFG batch 2), seed 42."""
     import time
     from PIL import Image
-    from fie_amd import hip, stack
-    from fie_amd.pipe import HipImg2ImgPipeline
-    from oracle import metrics
+    from fie_amd import hip
+    from oracle import pipeline as opipe
     from test_pipeline_gpu import synth_image
-    ctx32 = hip.context(0, torch.float32)
-    cfgs, sds = stack.synthetic_stack("ssd-1b", True, device=fie.device, dtype=torch.float32)
-    p32 = HipImg2ImgPipeline(ctx32, cfgs, sds)
-    del sds
+    cfgs, sds32, pipe = full
     img = synth_image(123, 512).resize((1024, 1024), Image.LANCZOS)
     ctrl = Image.fromarray(hip.canny_rgb(np.asarray(img)))
-    kw = dict(prompt="a slanted [rusty] mountain bicycle on the road in front of a building", negative_prompt="", image=img,
-              control_image=ctrl, strength=0.5, num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5)
-    big.use_graph = False
-    p32.use_graph = False
-    a = big(generator=torch.Generator("cpu").manual_seed(42), **kw).images[0]
+    ids = lambda texts: (pipe.tok_l(texts), pipe.tok_g(texts))
+    import os
+    torch.set_num_threads(min(16, os.cpu_count() or 16))      # the GPU box shares its cores: torch's default (one thread per visible core) oversubscribes them
     t0 = time.time()
-    b = p32(generator=torch.Generator("cpu").manual_seed(42), **kw).images[0]
-    dt = time.time() - t0
-    s512, s1024 = metrics.ssim(a, b), metrics.ssim(a, b, size=None)
-    d = np.abs(np.asarray(a).astype(int) - np.asarray(b).astype(int))
-    print(f"fp16 vs fp32 HIP @1024^2: SSIM(512)={s512:.5f} SSIM(1024)={s1024:.5f} max|du8|={d.max()} mean|du8|={d.mean():.3f}; "
-          f"fp32 edit {dt:.2f}s")
+    ref = opipe.run(sds32, cfgs, img, ctrl, ids([_PROMPT]), ids([""]), generator=torch.Generator("cpu").manual_seed(42), **_EDIT_KW)
+    print(f"oracle edit @1024^2: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads")
+    return img, ctrl, ref
+
+
+def _compare(name, out, ref):
+    from oracle import metrics
+    s512, s1024 = metrics.ssim(out, ref), metrics.ssim(out, ref, size=None)
+    d = np.abs(np.asarray(out).astype(int) - np.asarray(ref).astype(int))
+    print(f"{name} vs oracle @1024^2: SSIM(512)={s512:.5f} SSIM(1024)={s1024:.5f} max|du8|={d.max()} mean|du8|={d.mean():.4f}")
     assert s512 >= 0.99 and s1024 >= 0.99
+    return d.max()
+
+
+def test_full_size_edit_fp16_vs_oracle(full, oracle_edit):
+    """north_star gate at BASELINE size: the fp16 HIP edit against the oracle's edit, SSIM >= 0.99 at the metric resolution
+    (512x512 LANCZOS, reference src/metrics.py:227-231) and at full resolution; eager and hipGraph replay give one image."""
+    cfgs, sds32, pipe = full
+    img, ctrl, ref = oracle_edit
+    outs = []
+    for use_graph in (False, True):
+        pipe.use_graph = use_graph
+        outs.append(np.asarray(pipe(prompt=_PROMPT, negative_prompt="", image=img, control_image=ctrl,
+                                    generator=torch.Generator("cpu").manual_seed(42), **_EDIT_KW).images[0]))
+    assert pipe.last_stats == dict(unet_evals=2, cfg_batch=2, latent_hw=(128, 128), images=1)
+    assert np.array_equal(outs[0], outs[1])
+    _compare("fp16 HIP edit", outs[0], ref)
+
+
+def test_full_size_edit_fp32_vs_oracle(full, oracle_edit, fie):
+    """The exact-fp32 HIP path (`use_full_precision` / `--quality_mode`) against the same oracle edit: it is the on-GPU stand-in
+    for the oracle in the A/B tools, so it has to earn that at full size too (<= 2 u8 levels expected)."""
+    from fie_amd import hip, stack
+    from fie_amd.pipe import HipImg2ImgPipeline
+    cfgs, sds32, _ = full
+    img, ctrl, ref = oracle_edit
+    ctx32 = hip.context(0, torch.float32)
+    p32 = HipImg2ImgPipeline(ctx32, cfgs, sds32)
+    p32.use_graph = False
+    out = np.asarray(p32(prompt=_PROMPT, negative_prompt="", image=img, control_image=ctrl,
+                         generator=torch.Generator("cpu").manual_seed(42), **_EDIT_KW).images[0])
+    dmax = _compare("fp32 HIP edit", out, ref)
+    assert dmax <= 4

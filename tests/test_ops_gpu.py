@@ -240,9 +240,11 @@ def test_clip_embed(fie):
     assert rel_err(out, ref) < 2e-3
 
 
-@pytest.mark.parametrize("code", [1, 2, 3, 42, 43, 44, 46, 47, 51, 52, 54, 61, 62, 81, 82, 95, 96, 1042, 2042, 1062, 2081])
+@pytest.mark.parametrize("code", [1, 2, 3, 42, 43, 44, 46, 47, 51, 52, 54, 61, 62, 81, 82, 95, 96, 1042, 2042, 1062, 2081,
+                                  20096, 30096, 40096, 30095, 20051, 30047, 20054, 40052, 30042, 20043, 21096, 32047])
 def test_gemm_conv_every_shipped_kernel(fie, code):
-    """Every kernel / tile the launch table can select (gemm_conv.hip kTiles; + 2000 = m-tiles-fastest order) gives the
+    """Every kernel / tile the launch table can select (gemm_conv.hip kTiles; + 2000 = m-tiles-fastest order; + 10000 * s =
+    split-K over s blocks per tile, which falls back to fewer slices where a slice would get under 4 K-steps) gives the
     reference result on GEMMs with ragged M / N / K tails and on convs with stride 2, asymmetric pad and fused upsample; a
     code the shape is not eligible for raises instead of launching."""
     from fie_amd import hip
@@ -439,6 +441,7 @@ def test_gemm_autotune_picks_by_measurement_and_keeps_results(fie):
     rule_kernel = hip.last_gemm_kernel(fie)
     n0 = fie.autotune_report()[0]
     try:
+        fie.splitk(False)                               # split-K changes the fp32 summation order: its own test below
         fie.autotune(1)
         inplace = res0.clone()
         got_res = fie.gemm(ad, wp, n, bias=bd, residual=inplace, out=inplace).clone()      # tuned on this call
@@ -463,8 +466,101 @@ def test_gemm_autotune_picks_by_measurement_and_keeps_results(fie):
         assert fie.autotune_report()[0] == n0 + 2 and torch.equal(cap, ref[:1024])
     finally:
         fie.autotune(0)
+        fie.splitk(True)
     fie.conv3x3(x, wc, 192)
     assert hip.last_gemm_kernel(fie) == rule_kernel
+
+
+def test_split_k_in_launch_reduction(fie):
+    """Split-K for the M = 2048 class (include/fie.h: fie_splitk_workspace; gemm_common.h: splitk_reduce): the K-steps of a tile are
+    dealt to s blocks, the block that arrives last sums the fp32 slabs in slice order and runs the epilogue.  Checked: the result
+    against fp32 torch and against the unsplit kernel (same tile) with every epilogue option (bias, row bias, activation, scale,
+    in-place residual, GEGLU); conv with its 1x1 side inputs, the 2x-upsampling parity conv, GroupNorm sums from the epilogue;
+    bit-identical repeats (the sum order does not depend on which block came last) back to back on ONE workspace with changing
+    inputs (a stale slab or counter would show), also while a second stream runs split GEMMs on ITS workspace; the counters are
+    left zero; without a workspace the launch falls back to the unsplit kernel."""
+    from fie_amd import hip
+    lib = hip.lib()
+    m, n, k = 2048, 1280, 5120
+    w = rnd(n, k, seed=2, scale=k ** -0.5)
+    wp = fie.pack_linear(w.to(DEV))
+    bias, rb = rnd(n, seed=3).to(DEV), rnd(2, n, seed=5).to(DEV)
+    try:
+        for code in (30096, 20096, 40096, 20095, 30047, 20054, 30052):
+            a, res = rnd(m, k, seed=code), rnd(m, n, seed=code + 1)
+            ad = a.to(DEV)
+            ref = (a.float() @ w.float().T + bias.float().cpu() + rb.float().cpu().repeat_interleave(m // 2, 0))
+            ref = F.silu(ref) * 0.5 + res.float()
+            fie.force_tile(code)
+            inplace = res.to(DEV).clone()
+            out = fie.gemm(ad, wp, n, bias=bias, rowbias=rb, rows_per_batch=m // 2, residual=inplace, out=inplace, scale=0.5, act=hip.ACT_SILU)
+            assert f"split-K {code // 10000}" in hip.last_gemm_kernel(fie), hip.last_gemm_kernel(fie)
+            assert rel_err(out, ref) < 3e-3, code
+            fie.force_tile(code % 10000)
+            plain = fie.gemm(ad, wp, n, bias=bias, rowbias=rb, rows_per_batch=m // 2, residual=res.to(DEV), scale=0.5, act=hip.ACT_SILU)
+            assert "split-K" not in hip.last_gemm_kernel(fie)
+            assert rel_err(out, plain.float()) < 1.5e-3, code           # fp32 summation order differs: last f16 bit only
+        # GEGLU (FF1-type) and ragged M / N / K tails
+        fie.force_tile(30096)
+        a, wg, bg = rnd(1000, 1288, seed=11), rnd(520, 1288, seed=12, scale=1288 ** -0.5), rnd(520, seed=13)
+        out = fie.gemm(a.to(DEV), fie.pack_linear(wg.to(DEV), geglu=True), 520, bias=bg.to(DEV), act=hip.ACT_GEGLU)
+        full = a.float() @ wg.float().T + bg.float()
+        assert rel_err(out, full[:, :260] * F.gelu(full[:, 260:])) < 3e-3
+        # repeats on one workspace with changing inputs; a second stream splitting on its own workspace meanwhile
+        fie.force_tile(30096)
+        side = torch.cuda.Stream()
+        a0, a1 = rnd(m, k, seed=21).to(DEV), rnd(m, k, seed=22).to(DEV)
+        first = [fie.gemm(a0, wp, n, bias=bias).clone(), fie.gemm(a1, wp, n, bias=bias).clone()]
+        torch.cuda.synchronize()
+        for it in range(12):
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    other = fie.gemm(a1 if it % 2 else a0, wp, n, bias=bias)
+            got = fie.gemm(a0 if it % 2 else a1, wp, n, bias=bias)
+            torch.cuda.synchronize()
+            assert torch.equal(got, first[(it + 1) % 2]) and torch.equal(other, first[it % 2]), it
+        for ws in fie._sk_ws.values():
+            assert int(ws[:16384].view(torch.int32).abs().sum()) == 0           # every launch leaves its arrival counters zero
+        # conv 3x3 + its 1x1 side inputs, 2x-upsampling parity conv, GroupNorm sums from the split epilogue
+        x = rnd(2, 32, 32, 256, seed=31).to(DEV)
+        wt = rnd(512, 256, 3, 3, seed=32, scale=(9 * 256) ** -0.5)
+        wc = fie.pack_conv3x3(wt.to(DEV))
+        gam, bet = torch.ones(512, dtype=torch.float16, device=DEV), torch.zeros(512, dtype=torch.float16, device=DEV)
+        ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wt.float(), None, padding=1)
+        for code in (30096, 20095, 40052):
+            fie.force_tile(code)
+            y = fie.conv3x3(x, wc, 512, gn_groups=32)
+            assert "split-K" in hip.last_gemm_kernel(fie)
+            assert rel_err(y.permute(0, 3, 1, 2), ref) < 3e-3, code
+            assert getattr(y, "_gn_tag", None) is not None
+            fie.force_tile(0)
+            gn = fie.groupnorm(y, gam, bet, 32, 1e-5, True)              # consumes the epilogue's sums
+            gref = F.silu(F.group_norm(y.float().permute(0, 3, 1, 2), 32, eps=1e-5))
+            assert rel_err(gn.permute(0, 3, 1, 2), gref) < 4e-3, code
+            fie.force_tile(code)
+            w4 = fie.pack_conv_up2x(wt.to(DEV))
+            up = fie.conv_up2x(x, w4, 512)
+            uref = F.conv2d(F.interpolate(x.float().cpu().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"), wt.float(), None, padding=1)
+            assert rel_err(up.permute(0, 3, 1, 2), uref) < 4e-3, code
+            x2, x3 = rnd(2 * 32 * 32, 128, seed=33).to(DEV), rnd(2 * 32 * 32, 64, seed=34).to(DEV)
+            w1 = rnd(512, 192, seed=35, scale=192 ** -0.5)
+            wplus = torch.cat([wc[:, :9 * 256], fie.pack_linear(w1.to(DEV))[:, :192]], 1).contiguous()
+            yp = fie.conv3x3_plus(x, wplus, 512, x2, x3)
+            pref = ref + (torch.cat([x2, x3], 1).float().cpu() @ w1.float().T).view(2, 32, 32, 512).permute(0, 3, 1, 2)
+            assert rel_err(yp.permute(0, 3, 1, 2), pref) < 3e-3, code
+        # no workspace bound: the same forced code runs unsplit
+        fie.force_tile(30096)
+        assert lib.fie_splitk_workspace(fie.h, None, 0) == 0
+        fie._sk_bound = "unbound"
+        saved, fie.splitk_bytes = fie.splitk_bytes, 0
+        try:
+            out = fie.gemm(a0, wp, n, bias=bias)
+            assert "split-K" not in hip.last_gemm_kernel(fie) and rel_err(out, first[0].float()) < 1.5e-3
+        finally:
+            fie.splitk_bytes = saved
+            fie._sk_bound = None
+    finally:
+        fie.force_tile(0)
 
 
 @pytest.mark.parametrize("cout,code", [(128, 0), (256, 54), (512, 81), (128, 52), (256, 62), (128, 42), (512, 96), (256, 43)])
