@@ -70,10 +70,11 @@ def load_items():
         return list(csv.DictReader(f))
 
 
-def cpu_baseline(editor, cfgs, job_args, evals, nb):
-    """Time the CPU fp32 oracle on a bounded sample: CLIP (batch nb) + VAE encode + ONE ControlNet+UNet evaluation at
-    batch 1 + VAE decode at 1024^2, then assemble the benchmark configuration's time from those parts."""
-    from oracle import nets, pipeline as opipe
+def cpu_baseline(editor, cfgs, job_args, evals, nb, strength, guidance):
+    """ONE whole edit of the benchmark configuration through the CPU fp32 oracle (oracle.pipeline.run: CLIP x2 at batch nb, VAE
+    encode, evals x (ControlNet + UNet) at CFG batch nb, LCM steps, VAE decode), timed end to end on this host's cores: the same
+    workload as one timed GPU step, not an assembly of parts."""
+    from oracle import pipeline as opipe
     from fie_amd import weights
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -85,38 +86,44 @@ def cpu_baseline(editor, cfgs, job_args, evals, nb):
         sds[k] = {n: v.float() for n, v in weights.synth_state_dict(cfgs[k], seed=1234 + s, dtype=torch.float16).items()}
     pipe = editor.pipe
     img, ctrl, prompt = job_args
-    log("cpu_baseline: weights ready, timing CLIP")
-    with torch.no_grad():
-        t0 = time.time()
-        ids = (pipe.tok_l([prompt] * nb), pipe.tok_g([prompt] * nb))
-        pe, pooled = opipe.encode_prompt(sds, cfgs, *ids)
-        t_clip = time.time() - t0
-        log(f"cpu_baseline: clip {t_clip:.1f}s; timing VAE encode")
-        t0 = time.time()
-        x = opipe.pil_to_float(img, True)
-        mean, _ = nets.vae_encode_moments(sds["vae"], cfgs["vae"], x)
-        t_enc = time.time() - t0
-        log(f"cpu_baseline: vae encode {t_enc:.1f}s; timing one ControlNet+UNet eval")
-        lat = mean * cfgs["vae"]["scaling_factor"]
-        cond = opipe.pil_to_float(ctrl, False)
-        tid = torch.tensor([[1024., 1024., 0, 0, 1024., 1024.]])
-        t0 = time.time()
-        down, mid = nets.controlnet_forward(sds["controlnet"], cfgs["controlnet"], lat, 499, pe[:1], cond, 0.5, pooled[:1], tid)
-        eps = nets.unet_forward(sds["unet"], cfgs["unet"], lat, 499, pe[:1], pooled[:1], tid, down, mid)
-        t_eval = time.time() - t0
-        log(f"cpu_baseline: eval {t_eval:.1f}s; timing VAE decode")
-        t0 = time.time()
-        nets.vae_decode(sds["vae"], cfgs["vae"], (lat - 0.1 * eps) / cfgs["vae"]["scaling_factor"])
-        t_dec = time.time() - t0
-    est = t_clip + t_enc + t_dec + evals * nb * t_eval
-    return {"value": 1.0 / est, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": (f"oracle/ fp32 torch-CPU restatement, 1 image 1024^2: CLIPx2 batch {nb} {t_clip:.1f}s + VAE encode "
-                       f"{t_enc:.1f}s + one ControlNet+UNet eval at batch 1 {t_eval:.1f}s + VAE decode {t_dec:.1f}s measured; "
-                       f"image time assembled as clip + enc + dec + {evals}x{nb} evals = {est:.1f}s")}
+    ids = lambda texts: (pipe.tok_l(texts), pipe.tok_g(texts))
+    log(f"cpu_baseline: weights ready, timing one oracle edit on {cores} threads")
+    tr = {}
+    t0 = time.time()
+    out = opipe.run(sds, cfgs, img, ctrl, ids([prompt]), ids([""]), strength=strength, num_inference_steps=4, guidance_scale=guidance,
+                    controlnet_conditioning_scale=0.5, generator=torch.Generator("cpu").manual_seed(42), trace=tr)
+    dt = time.time() - t0
+    assert out.shape == (1024, 1024, 3) and len(tr["eps"]) == evals
+    log(f"cpu_baseline: one edit {dt:.1f}s")
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": (f"oracle/ fp32 torch-CPU restatement (oracle.pipeline.run), ONE whole 1024^2 edit of this configuration timed end to end: "
+                       f"CLIPx2 at batch {nb}, VAE encode, {evals} x (ControlNet + UNet) at CFG batch {nb}, LCM steps, VAE decode = {dt:.1f}s")}
 
 
-def time_unet_forward(pipe, job, iters=3):
-    """HIP-event time of one UNet forward (encode + decode, CFG batch) issued alone on the current stream."""
+def _graph_ms(fn, reps=5):
+    """Device time of `fn`'s launches captured as ONE hipGraph on the current stream and replayed (min of `reps`): what the production
+    path (hipGraph replay) spends on them, without the host's per-launch cost that an eager pass adds to chains of small kernels."""
+    fn()                                                # eager warm-up: lazy workspaces; tiles were tuned by the edits before
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    g.replay()
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    return best, out, g
+
+
+def time_unet_forward(pipe, job, iters=5):
+    """Device time of one UNet forward (encode + decode, CFG batch) alone on one stream, replayed from a hipGraph."""
     ctx, dev = pipe.ctx, pipe.ctx.device
     h, w = job["hw"]
     nb = job["nb"]
@@ -129,18 +136,81 @@ def time_unet_forward(pipe, job, iters=3):
     x = torch.zeros((nb, lh, lw, 8), device=dev, dtype=torch.float16)
     x[..., :4] = torch.randn((nb, lh, lw, 4), generator=g, device=dev, dtype=torch.float16)
     pipe.unet.begin_image(pooled, job["time_ids"])
-    best = None
-    for _ in range(iters + 1):
-        tb = pipe.unet.time_rowbias(job["t_dev"][0])
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    tb = pipe.unet.time_rowbias(job["t_dev"][0])
+
+    def fwd():
         skips, mid = pipe.unet.encode(pipe.unet.conv_in(ctx, x), tb, text, 77)
-        pipe.unet.decode(mid, skips, tb, text, 77)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)
-        best = ms if best is None else min(best, ms)
-    return best
+        return pipe.unet.decode(mid, skips, tb, text, 77)
+
+    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        ms, _, _ = _graph_ms(fwd, iters)
+    return ms
+
+
+def stage_graph_ms(pipe, job, fl, reps=5):
+    """Every stage of one edit captured as its OWN single-stream hipGraph and replayed: device ms and TFLOP/s per stage (the
+    production graph additionally overlaps CLIP with the VAE encode and the UNet encoder with the ControlNet trunk, so the whole
+    edit is shorter than the sum).  Mirrors pipe.run_device() for one image."""
+    ctx, dev = pipe.ctx, pipe.ctx.device
+    h, w = job["hw"]
+    nb, steps = job["nb"], job["steps"]
+    lh, lw = h // 8, w // 8
+    hw = lh * lw
+    sf = pipe.cfgs["vae"]["scaling_factor"]
+    st0 = steps[0]
+    out, keep = {}, []
+    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        def clip():
+            pl, _ = pipe.clip_l(job["ids_l"])
+            pg, pooled = pipe.clip_g(job["ids_g"], eos_rows=job["eos_rows"])
+            return torch.cat([pl, pg], dim=1), pooled
+        ms, (text, pooled), g = _graph_ms(clip, reps); keep.append(g)
+        out["clip"] = (ms, nb * fl["clip"])
+        latents = torch.empty((1, hw, 4), device=dev, dtype=torch.float32)
+        model_in = torch.empty((nb, lh, lw, 8), device=dev, dtype=ctx.dtype)
+
+        def enc():
+            x_img = ctx.pixels_in(job["img_u8"], True)
+            cond = ctx.pixels_in(job["ctl_u8"], False)
+            moments, _ = pipe.vae.encode_moments(x_img)
+            ctx.latent_prep(moments, job["noises"][0], job["noises"][1], hw, sf, st0["sqrt_ab"], st0["sqrt_1mab"], latents[0], model_in)
+            return cond
+        ms, cond, g = _graph_ms(enc, reps); keep.append(g)
+        out["vae_encode"] = (ms, fl["vae_encode"])
+        pipe.unet.begin_image(pooled, job["time_ids"])
+        pipe.controlnet.begin_image(pooled, job["time_ids"])
+        cond_emb = pipe.controlnet.cond_embedding(cond)
+        if nb > 1:
+            cond_emb = cond_emb.repeat_interleave(nb, dim=0)
+        t_dev = job["t_dev"][0]
+        tb_u, tb_c = pipe.unet.time_rowbias(t_dev), pipe.controlnet.time_rowbias(t_dev)
+
+        def cn():
+            return pipe.controlnet.encode_cond(model_in, cond_emb, tb_c, text, 77)
+        ms, (c_skips, c_mid), g = _graph_ms(cn, reps); keep.append(g)
+        out["controlnet_trunk (per eval)"] = (ms, nb * fl["controlnet"])
+
+        def uenc():
+            return pipe.unet.encode(pipe.unet.conv_in(ctx, model_in), tb_u, text, 77)
+        ms, (skips, mid), g = _graph_ms(uenc, reps); keep.append(g)
+
+        def udec():
+            sk, m = pipe.controlnet.add_residuals(c_skips, c_mid, job["cn_scale"], skips, mid)
+            return pipe.unet.decode(m, sk, tb_u, text, 77)
+        ms2, eps, g = _graph_ms(udec, reps); keep.append(g)
+        out["unet_encoder (per eval)"] = (ms, None)
+        out["unet_decoder + zero-conv adds (per eval)"] = (ms2, None)
+        out["unet (per eval)"] = (ms + ms2, nb * fl["unet"])
+        decode_in = torch.zeros((1, lh, lw, 8), device=dev, dtype=ctx.dtype)
+        decode_in[..., :4] = (latents.view(1, lh, lw, 4) / sf).to(ctx.dtype)
+
+        def dec():
+            return ctx.pixels_out(pipe.vae.decode(decode_in))
+        ms, _, g = _graph_ms(dec, reps); keep.append(g)
+        out["vae_decode"] = (ms, fl["vae_decode_executed"] if "vae_decode_executed" in fl else fl["vae_decode"])
+    torch.cuda.synchronize()
+    return {k: {"ms": round(ms, 3), **({"tflops": round(f / (ms * 1e-3) / 1e12, 1), "frac_of_mfma_peak": round(f / (ms * 1e-3) / 1e12 / PEAK_F16_DENSE_TFLOPS, 4)} if f else {})}
+            for k, (ms, f) in out.items()}
 
 
 def pmc_traffic(kernel, m, n, k, path=None):
@@ -391,6 +461,8 @@ def main():
     pipe.timing = None
     dominant = time_dominant_kernel(pipe, nb)
     fl = flops.image_flops(cfgs, evals, nb)
+    stage_graphs = stage_graph_ms(pipe, job0, fl) if not args.no_graph else {}
+    log(f"stage graphs (single stream each): {stage_graphs}")
     # roofline pass: UNet alone on one stream (the overlapped production schedule interleaves ControlNet kernels)
     unet_ms_per_fwd = time_unet_forward(pipe, job0)
     unet_tflops = fl["unet"] * nb / (unet_ms_per_fwd * 1e-3) / 1e12
@@ -447,6 +519,9 @@ def main():
                                           "frac": round(unet_tflops / PEAK_F16_DENSE_TFLOPS, 4),
                                           "algorithmic_tflop": round(fl["unet"] * nb / 1e12, 3), "ms": round(unet_ms_per_fwd, 3)}},
             "stage_ms": {k: round(v, 2) for k, v in stage.items()},
+            "stage_ms_what": "eager single pass with HIP events (includes the host's per-launch cost on chains of small kernels: CLIP)",
+            "stage_graph_ms": stage_graphs,
+            "stage_graph_ms_what": "every stage as its own single-stream hipGraph, replayed: device time + algorithmic TFLOP/s; the production graph also overlaps CLIP || VAE encode and UNet encoder || ControlNet trunk",
             "host_ms_per_edit": {k: round(v, 2) for k, v in marks.items()},
             "image_tflops": round(image_tflops, 2),
             "per_rank_seconds": [round(x, 4) for x in per_rank],
@@ -454,7 +529,7 @@ def main():
         }
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(editor, cfgs, (first_inp, first_ctrl, first_prompt), evals, nb)
+            out["cpu_baseline"] = cpu_baseline(editor, cfgs, (first_inp, first_ctrl, first_prompt), evals, nb, args.strength, args.guidance)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -159,6 +159,12 @@ int fie_vae_encode(fie_ctx* ctx) { return run_graph(ctx, "vae_encode"); }
 int fie_vae_decode(fie_ctx* ctx) { return run_graph(ctx, "vae_decode"); }
 int fie_clip_text_forward(fie_ctx* ctx) { return run_graph(ctx, "clip_text_forward"); }
 
+int fie_ctx_error_flag(fie_ctx* ctx, void* device_word) {
+    FIE_REQUIRE(ctx != nullptr, "fie_ctx_error_flag: ctx is NULL");
+    ctx->err_flag = static_cast<unsigned*>(device_word);
+    return FIE_OK;
+}
+
 int fie_ctx_set_stream(fie_ctx* ctx, void* stream) {
     FIE_REQUIRE(ctx != nullptr, "fie_ctx_set_stream: ctx is NULL");
     ctx->stream = (hipStream_t)stream;

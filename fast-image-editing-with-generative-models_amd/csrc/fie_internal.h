@@ -55,11 +55,13 @@ struct fie_ctx {
     int64_t gn_target_rows = 0;
     int gn_target_groups = 0;
     int gn_onepass = 1;                      // fie_debug_gn_onepass: 0 = always the three-kernel GroupNorm
+    unsigned* err_flag = nullptr;            // fie_ctx_error_flag: device word kernels set to a FIE_DEVERR_* code instead of failing silently
     void* sk_ws = nullptr;                   // fie_splitk_workspace: [4096 arrival counters (zero between launches)][fp32 partial-tile slabs]
     int64_t sk_bytes = 0;
     int splitk_mode = 1;                     // fie_debug_splitk: 0 = never split K, 1 = where the tuner / an override says so
     int autotune = 0;                        // fie_gemm_autotune: time the eligible tiles at a shape's first eager launch
     std::map<fie_tune_key, int> tuned;
+    int tune_exclude[16] = {0};              // fie_debug_tune_exclude: tile codes the tuner must not offer (10000 = every split-K variant); 0-terminated
     void* tune_buf = nullptr;                // scratch output of the timing launches
     void* tune_flush = nullptr;              // 384 MB written between timed launches: cold weights, as inside the network
     size_t tune_bytes = 0;

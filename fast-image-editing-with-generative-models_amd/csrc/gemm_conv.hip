@@ -220,16 +220,18 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             a_off2[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda2 * 2u + c8 * 16u : kOob;
             a_off3[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda3 * 2u + c8 * 16u : kOob;
         } else {
-            a_off1[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda1 * 2u + c8 * 16u : kOob;
-            a_off2[i] = a_ok[i] ? (unsigned)m * (unsigned)p.lda2 * 2u + c8 * 16u : kOob;
+            a_off1[i] = a_off2[i] = a_off3[i] = a_img[i] = 0;          // GEMM: a_base1 / a_base2 below
             a_ih[i] = a_iw[i] = 0;
-            a_img[i] = 0;
-            a_off3[i] = 0;
         }
     }
-    unsigned w_off[RW];
-#pragma unroll
-    for (int i = 0; i < RW; ++i) w_off[i] = (unsigned)(ln0 + (wave + NW * i) * 8 + lr) * (unsigned)p.ldw * 2u + c8 * 16u;
+    // GEMM view: a lane's row groups are NW * 8 rows apart, so ONE per-lane offset (+ a uniform stride per group) serves all of them.
+    // Rows >= M need no mask: their offset m * lda * 2 is >= the descriptor's extent ((M - 1) * lda + K1) * 2 (lda >= K1), so the range
+    // check returns zeros (and (M + 255) * lda * 2 stays far below 2^32 for operands < 2 GiB).
+    const unsigned a_base1 = (unsigned)(lm0 + wave * 8 + lr) * (unsigned)p.lda1 * 2u + c8 * 16u;
+    const unsigned a_base2 = (unsigned)(lm0 + wave * 8 + lr) * (unsigned)p.lda2 * 2u + c8 * 16u;
+    const unsigned a_step1 = (unsigned)(NW * 8) * (unsigned)p.lda1 * 2u, a_step2 = (unsigned)(NW * 8) * (unsigned)p.lda2 * 2u;
+    const unsigned w_base = (unsigned)(ln0 + wave * 8 + lr) * (unsigned)p.ldw * 2u + c8 * 16u;       // weights are padded to whole tiles: no tail
+    const unsigned w_step = (unsigned)(NW * 8) * (unsigned)p.ldw * 2u;
 
     const int csteps = MODE == 2 ? p.Cin / BK : 1;
     const int k1_steps = p.K1 / BK;            // GEMM: K-steps served by A1 (K1 % 64 == 0 unless K1 == K)
@@ -272,15 +274,15 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             if (ktail && kt == nk_all - 1) {           // last, partial K-step: columns >= K read as zero
                 const bool in_k = kt * BK + c8 * 8 < p.K;
 #pragma unroll
-                for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, in_k ? a_off1[i] : kOob, (unsigned)kt * (BK * 2));
+                for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, in_k ? a_base1 + (unsigned)i * a_step1 : kOob, (unsigned)kt * (BK * 2));
             } else if (kt < k1_steps || k1_steps == 0) {
                 const unsigned so = (unsigned)kt * (BK * 2);
 #pragma unroll
-                for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, a_off1[i], so);
+                for (int i = 0; i < RA; ++i) bload16(rs_a1, sa + (wave + NW * i) * 512, a_base1 + (unsigned)i * a_step1, so);
             } else {
                 const unsigned so = (unsigned)(kt - k1_steps) * (BK * 2);
 #pragma unroll
-                for (int i = 0; i < RA; ++i) bload16(rs_a2, sa + (wave + NW * i) * 512, a_off2[i], so);
+                for (int i = 0; i < RA; ++i) bload16(rs_a2, sa + (wave + NW * i) * 512, a_base2 + (unsigned)i * a_step2, so);
             }
         }
     };
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         half_t* sw = smem + stage * STAGE + BM * BK;
         const unsigned sow = (unsigned)kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < RW; ++i) bload16(rs_w, sw + (wave + NW * i) * 512, w_off[i], sow);
+        for (int i = 0; i < RW; ++i) bload16(rs_w, sw + (wave + NW * i) * 512, w_base + (unsigned)i * w_step, sow);
     };
 
     f32x4 acc[FN][FM];
@@ -394,12 +396,33 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
                 else if (NW == 8) issue_w(kbeg + kt + ST - 1, fill);
             }
             stamp(1 + 3 * kk);                             // 1 / 4: DMA issue
-            f16x8 fw[FN], fa[FM];
-            frags(fw, fa, sa, kk);
-            if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            stamp(2 + 3 * kk);                             // 2 / 5: fragment reads issued and landed
-            mfmas(fw, fa);
-            stamp(3 + 3 * kk);                             // 3 / 6: 16 MFMAs issued
+            if constexpr (FM * FN > 16) {
+                // 256x256 / 256x320: the activation fragments in two halves (13 fragments + 160 accumulators would not fit 256 VGPRs)
+                constexpr int HM = FM / 2;
+                const half_t* sw = sa + BM * BK;
+                f16x8 fw[FN];
+#pragma unroll
+                for (int i = 0; i < FN; ++i) fw[i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * WN + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    f16x8 fa[HM];
+#pragma unroll
+                    for (int j = 0; j < HM; ++j) fa[j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + (jh * HM + j) * 16 + fr, kk * 4 + fq));
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < FN; ++i)
+#pragma unroll
+                        for (int j = 0; j < HM; ++j) acc[i][jh * HM + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][jh * HM + j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+            } else {
+                f16x8 fw[FN], fa[FM];
+                frags(fw, fa, sa, kk);
+                if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                stamp(2 + 3 * kk);                         // 2 / 5: fragment reads issued and landed
+                mfmas(fw, fa);
+                stamp(3 + 3 * kk);                         // 3 / 6: 16 MFMAs issued
+            }
         }
         stage = stage + 1 == ST ? 0 : stage + 1;
         fill = fill + 1 == ST ? 0 : fill + 1;
@@ -408,10 +431,12 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     if constexpr (FM * FN <= 16) {                         // split-K: only the block that draws the tile's last ticket goes on, with the summed slices
         if (nsplit > 1 && !splitk_reduce<FM, FN, NW>(p, acc, tile_all, slice, tid, smem)) return;
     }
-    if constexpr (FM * FN > 16) {                          // 256x256: two column halves, see gemm8.hip
-        static_assert(FN == 4, "");
-        epilogue<FM, 2, WM, WN, true>(p, reinterpret_cast<f32x4(&)[2][FM]>(acc[0]), m0, n0, wm, wn, lane);
-        epilogue<FM, 2, WM, WN, true>(p, reinterpret_cast<f32x4(&)[2][FM]>(acc[2]), m0, n0 + 32, wm, wn, lane);
+    if constexpr (FM * FN > 16) {                          // 256x256 / 256x320: column chunks of two fragments (register pressure, see gemm8.hip)
+#pragma unroll
+        for (int c = 0; c < FN / 2; ++c)
+            epilogue<FM, 2, WM, WN, true>(p, reinterpret_cast<f32x4(&)[2][FM]>(acc[2 * c]), m0, n0 + 32 * c, wm, wn, lane);
+        if constexpr (FN & 1)
+            epilogue<FM, 1, WM, WN, true>(p, reinterpret_cast<f32x4(&)[1][FM]>(acc[FN - 1]), m0, n0 + 16 * (FN - 1), wm, wn, lane);
     } else {
         epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane);
     }
@@ -450,6 +475,8 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
 //                  the 32x32-latent convs lose nothing on cold weights with it, 7-9 % with 128x128)
 //   51             gemm3_kernel  128x128, 3 stages, 8 waves
 //   61 / 62        gemm3_kernel  256x256 x 2 stages / 256x128 x 3 stages, 8 waves
+//   63             gemm3_kernel  256x320 x 2 stages, 8 waves (wave tile 128x80): exactly ONE tile per CU for the FF1 projection M 2048 x N 10240
+//                  (256 tiles) and two rounds for M 8192 x N 5120; 142 FLOP per staged byte pair against 85 for 256x128
 //   + 1000 / + 2000  force the tile order (n-tiles / m-tiles fastest); plain codes estimate it
 //   95 / 96        gemm3_kernel 51 / 62 with fragment reads one half K-step ahead of the MFMAs (the 4-wave and 2-stage tiles gain nothing from it)
 //   97 / 98 / 94   62 / 96 / 42 with in-kernel cycle stamps (fie_debug_gemm_stamps; slower, for tools/kstep_stamps.py only)
@@ -457,7 +484,7 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
 struct TileDim { int code, bm, bn; };
 constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {42, 128, 64}, {43, 64, 64},
                               {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256},
-                              {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
+                              {63, 256, 320}, {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
                               {52, 128, 128}, {47, 128, 96}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}};
 
 // Heuristic tile code for a shape (the default; the autotuner below and the debug hooks can replace it).
@@ -572,6 +599,10 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
         case 51: launch_ring<128, 128, 3, M3, 8>(ctx, a, grid); break;
         case 61: launch_ring<256, 256, 2, M3, 8>(ctx, a, grid); break;
         case 62: launch_ring<256, 128, 3, M3, 8>(ctx, a, grid); break;
+        case 63:
+            FIE_REQUIRE(MODE == 0, "tile code 63 (256x320) is built for the GEMM view only");
+            launch_ring<256, 320, 2, 0, 8>(ctx, a, grid);
+            break;
         case 52: launch_ring<128, 128, 2, M3, 8>(ctx, a, grid); break;
         case 47: launch_ring<128, 96, 3, M3, 4>(ctx, a, grid); break;
         case 54: launch_ring<192, 128, 2, M3, 8>(ctx, a, grid); break;
@@ -603,7 +634,7 @@ constexpr size_t kFlushBytes = 384u << 20;
 
 template <int MODE>
 int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
-    static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81, 47};          // 47 (128x96): FIE_TUNE_47=0 leaves it out
+    static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81, 63, 47};      // 47 (128x96): FIE_TUNE_47=0 leaves it out
     static const bool use47 = !(getenv("FIE_TUNE_47") && getenv("FIE_TUNE_47")[0] == '0');
     static const int kW8[] = {43, 42, 62, 52, 54};
     const size_t bytes = (size_t)a.M * (a.oscat ? 4 : 1) * (size_t)a.ldc * sizeof(half_t);     // a parity conv scatters its M rows over 4 M output rows
@@ -642,12 +673,18 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     int best = guess;
     float t_best = t_guess * 0.97f;                          // a challenger has to win by 3 %
     const int* cand = a.w_scale ? kW8 : kRing;
-    const int ncand = a.w_scale ? 5 : use47 ? 10 : 9;
+    const int ncand = a.w_scale ? 5 : use47 ? 11 : 10;
+    auto excluded = [&](int c) {
+        for (int e : ctx->tune_exclude)
+            if (e == c) return e != 0;
+        return false;
+    };
     for (int i = 0; i < ncand; ++i) {
         const int c = cand[i];
-        if (c == guess) continue;
+        if (c == guess || excluded(c)) continue;
         if ((c == 43 || c == 46) && blocks(64, 64) > 64 * ctx->num_cus) continue;       // tens of thousands of tiny tiles: never wins
         if ((c == 81 || c == 96 || c == 62) && 2 * blocks(256, 128) < ctx->num_cus) continue;
+        if (c == 63 && (MODE != 0 || a.N % 320 != 0 || 2 * blocks(256, 320) < ctx->num_cus)) continue;
         if (c == 81 && MODE == 1 && a.A2) continue;            // side inputs: ring kernels only
         const float tc = time_of(c);
         if (verbose) fprintf(stderr, ", %d %.1f", c, tc * 1e3f);
@@ -656,9 +693,10 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     // split-K: big tiles whose grid leaves CUs idle (the M = 2048 class: 80 tiles of 256x128 on 256 CUs) with the K-steps of a tile dealt
     // to 2-4 blocks, reduced in the launch (gemm_common.h: splitk_reduce).  Changes the fp32 summation order, so unlike the tile choice
     // it is visible in the last bit of some f16 outputs; fixed per (shape, choice), hence deterministic within a process.
-    if (!a.w_scale && ctx->sk_ws && ctx->splitk_mode) {
+    if (!a.w_scale && ctx->sk_ws && ctx->splitk_mode && !excluded(10000)) {
         static const struct { int code, bm, bn, per_cu; } kSplit[] = {{96, 256, 128, 1}, {95, 128, 128, 1}, {47, 128, 96, 1}, {54, 192, 128, 2}, {52, 128, 128, 2}};
         for (const auto& c : kSplit) {
+            if (excluded(c.code)) continue;
             const int64_t nb = blocks(c.bm, c.bn) * (a.oscat == 2 ? 4 : 1);
             if (nb >= ctx->num_cus * c.per_cu) continue;                 // the grid already fills the chip
             for (int sp = 2; sp <= 4; ++sp) {
@@ -753,6 +791,7 @@ hipError_t ring_attrs() {
     if (e == hipSuccess) e = ring_attr<128, 128, 3, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<256, 256, 2, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<256, 128, 3, MODE, 8>();
+    if (e == hipSuccess && MODE == 0) e = ring_attr<256, 320, 2, 0, 8>();
     if (e == hipSuccess) e = ring_attr<128, 128, 2, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<128, 96, 3, MODE, 4>();
     if (e == hipSuccess) e = ring_attr<192, 128, 2, MODE, 8>();
@@ -842,6 +881,21 @@ int fie_gemm_autotune(fie_ctx* ctx, int on) {
     return FIE_OK;
 }
 
+int fie_debug_tune_exclude(fie_ctx* ctx, const char* codes) {
+    FIE_REQUIRE(ctx != nullptr, "fie_debug_tune_exclude: ctx is NULL");
+    memset(ctx->tune_exclude, 0, sizeof(ctx->tune_exclude));
+    ctx->tuned.clear();                                   // choices made under the previous list are forgotten
+    int n = 0;
+    for (const char* q = codes; q && *q && n < 15;) {
+        char* end = nullptr;
+        const long v = strtol(q, &end, 10);
+        if (end == q) break;
+        if (v > 0) ctx->tune_exclude[n++] = (int)v;
+        q = *end == ',' ? end + 1 : end;
+    }
+    return n;
+}
+
 int fie_gemm_autotune_report(fie_ctx* ctx, char* buf, int cap) {
     FIE_REQUIRE(ctx != nullptr && buf != nullptr && cap > 0, "fie_gemm_autotune_report: bad argument");
     int n = 0;
@@ -863,12 +917,21 @@ int fie_debug_gemm_stamps(fie_ctx* ctx, void* buf) {
 
 const char* fie_debug_last_gemm_kernel(fie_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }
 
-static int take_gn_target(const char* who, fie_ctx* ctx, GemmArgs& a) {
-    if (!ctx->gn_target) return FIE_OK;
-    a.gn_partial = ctx->gn_target;
-    a.gn_rows = (int)ctx->gn_target_rows;
-    a.gn_G = ctx->gn_target_groups;
-    ctx->gn_target = nullptr;                               // one shot
+// The one-shot GroupNorm target (fie_gn_stats_target) is taken -- and the context disarmed -- at the very TOP of every GEMM / conv entry,
+// before any argument check can return: a call that fails validation must not leave it armed for an unrelated later launch (whose M
+// might not fit the buffer the target was sized for).
+struct GnTarget { float* partial; int64_t rows; int groups; };
+static GnTarget grab_gn_target(fie_ctx* ctx) {
+    GnTarget t = {nullptr, 0, 0};
+    if (ctx) { t = {ctx->gn_target, ctx->gn_target_rows, ctx->gn_target_groups}; ctx->gn_target = nullptr; }
+    return t;
+}
+
+static int take_gn_target(const char* who, const GnTarget& t, GemmArgs& a) {
+    if (!t.partial) return FIE_OK;
+    a.gn_partial = t.partial;
+    a.gn_rows = (int)t.rows;
+    a.gn_G = t.groups;
     FIE_REQUIRE(a.act != FIE_ACT_GEGLU && a.N % a.gn_G == 0, "%s: GroupNorm statistics: N=%d not divisible into %d groups", who, a.N, a.gn_G);
     a.gn_cg = a.N / a.gn_G;
     FIE_REQUIRE(a.gn_cg == 4 || a.gn_cg == 8 || a.gn_cg == 16, "%s: GroupNorm statistics need 4, 8 or 16 channels per group (got %d)", who, a.gn_cg);
@@ -879,6 +942,7 @@ static int take_gn_target(const char* who, fie_ctx* ctx, GemmArgs& a) {
 static int gemm_impl(const char* who, fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2,
                      const void* Wpacked, int64_t ldw, const float* w_scale, void* C, int64_t ldc, int M, int N, int K, const void* bias,
                      const void* rowbias, int64_t ld_rowbias, int rows_per_batch, const void* residual, int64_t ldr, float scale, int act) {
+    const GnTarget gn = grab_gn_target(ctx);
     FIE_REQUIRE(ctx && A1 && Wpacked && C, "%s: NULL ctx/A1/W/C", who);
     FIE_REQUIRE(M > 0 && N > 0 && K > 0, "%s: bad shape M=%d N=%d K=%d", who, M, N, K);
     FIE_REQUIRE(K % 8 == 0 && K1 % 8 == 0 && K1 > 0 && K1 <= K, "%s: K=%d K1=%d must be multiples of 8", who, K, K1);
@@ -896,7 +960,7 @@ static int gemm_impl(const char* who, fie_ctx* ctx, const void* A1, int64_t lda1
     a.a1_bytes = ((int64_t)(M - 1) * lda1 + K1) * 2;
     a.a2_bytes = A2 ? ((int64_t)(M - 1) * lda2 + (K - K1)) * 2 : 0;
     a.w_bytes = fie_roundup(N, 128) * ldw * (w_scale ? 1 : 2);
-    if (int rc = take_gn_target(who, ctx, a)) return rc;
+    if (int rc = take_gn_target(who, gn, a)) return rc;
     return launch<0>(ctx, a);
 }
 
@@ -920,6 +984,7 @@ static int conv_impl(const char* who, fie_ctx* ctx, const void* X, int B, int H,
                      const void* Wpacked, int64_t ldw, const float* w_scale, void* Y, int64_t ldc, int Cout, const void* bias,
                      const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ldr, float scale, int act,
                      const void* X2 = nullptr, int64_t ld2 = 0, int C2 = 0, const void* X3 = nullptr, int64_t ld3 = 0, int C3 = 0) {
+    const GnTarget gn = grab_gn_target(ctx);
     FIE_REQUIRE(ctx && X && Wpacked && Y, "%s: NULL ctx/X/W/Y", who);
     FIE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "%s: bad shape", who);
     FIE_REQUIRE(Cin % 8 == 0, "%s: Cin=%d must be a multiple of 8 (pad the tensor)", who, Cin);
@@ -952,7 +1017,7 @@ static int conv_impl(const char* who, fie_ctx* ctx, const void* X, int B, int H,
         FIE_REQUIRE(a.a2_bytes < (1ll << 31) && a.a3_bytes < (1ll << 31), "%s: side inputs too large", who);
     }
     a.w_bytes = fie_roundup(Cout, 128) * ldw * (w_scale ? 1 : 2);
-    if (int rc = take_gn_target(who, ctx, a)) return rc;
+    if (int rc = take_gn_target(who, gn, a)) return rc;
     return launch<1>(ctx, a);
 }
 
@@ -983,6 +1048,7 @@ int fie_conv3x3_plus_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, 
 int fie_conv_up2x_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, const void* W4, int64_t ldw, int Npad, void* Y, int64_t ldc,
                            int Cout, const void* bias, const void* rowbias, int64_t ld_rowbias, float scale, int act) {
     const char* who = "fie_conv_up2x_nhwc_f16";
+    const GnTarget gnt = grab_gn_target(ctx);               // GroupNorm sums of the [B, 2H, 2W, Cout] output: a quarter of the granules per parity
     FIE_REQUIRE(ctx && X && W4 && Y, "%s: NULL ctx/X/W/Y", who);
     FIE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % BK == 0 && Cout > 0 && Npad >= Cout, "%s: bad shape (Cin %% 64 == 0)", who);
     FIE_REQUIRE(act != FIE_ACT_GEGLU, "%s: GEGLU not supported", who);
@@ -990,10 +1056,9 @@ int fie_conv_up2x_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int
     FIE_REQUIRE(ldw % BK == 0 && ldw >= K, "%s: ldw=%lld must be a multiple of 64 covering 4*Cin", who, (long long)ldw);
     if (int e = check_epilogue(who, Cout, ldc, nullptr, 0, act)) return e;
     FIE_REQUIRE((int64_t)B * H * W * 4 < (1ll << 31), "%s: too many output pixels", who);
-    float* gn = ctx->gn_target;                             // GroupNorm sums of the [B, 2H, 2W, Cout] output: a quarter of the granules per parity
-    const int64_t gn_rows = ctx->gn_target_rows;
-    const int gn_groups = ctx->gn_target_groups;
-    ctx->gn_target = nullptr;
+    float* gn = gnt.partial;
+    const int64_t gn_rows = gnt.rows;
+    const int gn_groups = gnt.groups;
     if (gn) {
         FIE_REQUIRE(gn_rows == 4ll * H * W && (H * W) % 32 == 0 && Cout % gn_groups == 0, "%s: GroupNorm statistics: %lld rows per image for a %dx%d input", who, (long long)gn_rows, H, W);
         const int cg = Cout / gn_groups;

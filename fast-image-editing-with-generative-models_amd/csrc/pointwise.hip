@@ -30,13 +30,14 @@ __global__ void sinusoid_kernel(const float* vals, int B, int nvals, int dim, T*
 // owns a quarter of one neuron's K range (all its 16-byte weight loads are independent and in flight together; the four quarters
 // meet by two shuffles).  Between the layers the workgroups exchange the hidden vector through `ws` behind a counter barrier
 // (cdna_hip_programming.md Guideline 16: every storing wave drains, one agent-scope release + relaxed arrive per workgroup, relaxed
-// poll + ONE agent-scope acquire; E / 64 <= 256 workgroups are co-resident by grid size; the spin is bounded).  The last workgroup
+// poll + ONE agent-scope acquire; E / 64 <= 256 workgroups are co-resident by grid size; the spin is bounded, and a workgroup that
+// gives up says so: sync[2] of the workspace and the context's device error word, fie_ctx_error_flag, become non-zero).  The last workgroup
 // to leave resets the two counters, so the zero-initialised workspace is clean for the next launch on the same stream.
 constexpr int kTeMaxB = 4;
 
 __global__ __launch_bounds__(256) void time_embed_kernel(const float* t, int B, int C0, int E, const half_t* W1, const half_t* b1,
                                                          const half_t* W2, const half_t* b2, const half_t* add, int64_t ld_add,
-                                                         half_t* out, int64_t ld_out, half_t* hbuf, unsigned* sync) {
+                                                         half_t* out, int64_t ld_out, half_t* hbuf, unsigned* sync, unsigned* err) {
     extern __shared__ __attribute__((aligned(16))) half_t te_smem[];
     half_t* x = te_smem;                       // [B][C0]   sinusoid, storage type (as the unfused path stores it)
     half_t* h = te_smem + kTeMaxB * 512;       // [B][E]    hidden vector after the barrier
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* t, int B, 
         __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(2);
+        if (spins >= (1u << 22)) {             // gave up: the hidden vector may be incomplete.  Sticky words the host reads at its next sync
+            __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (err) __hip_atomic_store(err, FIE_DEVERR_TIME_EMBED_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -332,7 +337,7 @@ int fie_time_embed_f16(fie_ctx* ctx, const float* t, int B, int C0, int E, const
     half_t* hbuf = (half_t*)workspace;
     unsigned* sync = (unsigned*)((char*)workspace + (int64_t)kTeMaxB * E * sizeof(half_t));      // must be ZERO before the first launch
     fie_launch(ctx, time_embed_kernel, dim3(E / 64), dim3(256), (unsigned)lds, t, B, C0, E, (const half_t*)W1, (const half_t*)b1,
-               (const half_t*)W2, (const half_t*)b2, (const half_t*)add, ld_add, (half_t*)out, ld_out, hbuf, sync);
+               (const half_t*)W2, (const half_t*)b2, (const half_t*)add, ld_add, (half_t*)out, ld_out, hbuf, sync, ctx->err_flag);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

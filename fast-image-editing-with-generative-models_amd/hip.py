@@ -23,6 +23,7 @@ SIGNATURES = {
     "fie_version": [],
     "fie_ctx_create": [_I, _P, _c.POINTER(_P)],
     "fie_ctx_set_stream": [_P, _P],
+    "fie_ctx_error_flag": [_P, _P],
     "fie_ctx_destroy": [_P],
     "fie_program_begin": [_P, _c.POINTER(_P)],
     "fie_program_end": [_P],
@@ -83,6 +84,7 @@ SIGNATURES = {
     "fie_groupnorm_stats_nhwc_f16": [_P, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _P],
     "fie_gemm_autotune": [_P, _I],
     "fie_gemm_autotune_report": [_P, ctypes.c_char_p, _I],
+    "fie_debug_tune_exclude": [_P, ctypes.c_char_p],
     "fie_debug_gemm_probe": [_P, _I],
     "fie_debug_gemm_stamps": [_P, _P],
     "fie_splitk_workspace": [_P, _P, _L],
@@ -198,6 +200,10 @@ class Context:
         h = _P()
         _chk(lib().fie_ctx_create(device, None, ctypes.byref(h)))
         self.h = h
+        # device error word (include/fie.h: FIE_DEVERR_*): kernels that must give up set it; check_device_errors() reads it
+        self._err = torch.zeros(4, device=self.device, dtype=torch.int32)
+        self._err_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        _chk(lib().fie_ctx_error_flag(self.h, self._err.data_ptr()))
         self._stream = None
         self._gn_ws = {}
         self._gn_stats = {}
@@ -212,6 +218,23 @@ class Context:
         self.ws_tag = 0
         self._keep = None              # list collecting the tensors allocated while a program is being recorded (Context.record)
         self.w8 = False                # while True, pack_linear / pack_conv3x3 quantise eligible weights to fp8 e4m3 (see W8)
+
+    def fetch_device_errors(self):
+        """Queues the 16-byte D2H copy of the error word on the current stream (call before a synchronisation that happens anyway)."""
+        self._err_host.copy_(self._err, non_blocking=True)
+
+    def check_device_errors(self, fetch=True):
+        """Raises FieError when a kernel reported a device-side failure since the last check (clears the word)."""
+        if fetch:
+            self.fetch_device_errors()
+            torch.cuda.current_stream(self.device).synchronize()
+        code = int(self._err_host[0])
+        if code:
+            self._err.zero_()
+            self._err_host.zero_()
+            what = {1: "fie_time_embed_f16: the in-launch barrier timed out (a workgroup never arrived); the timestep embedding of that "
+                       "launch is invalid"}.get(code, "unknown device error")
+            raise FieError(f"device error {code}: {what}")
 
     def sync_stream(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
@@ -276,6 +299,10 @@ class Context:
     def autotune(self, on=True):
         """Per-shape tile autotune (include/fie.h: fie_gemm_autotune): first eager launch of a shape times the eligible tiles."""
         _chk(lib().fie_gemm_autotune(self.h, int(on)))                # 0 off, 1 tune new shapes, 2 remembered shapes only
+
+    def tune_exclude(self, codes):
+        """Tile codes ("63,96"; 10000 = all split-K variants) the tuner must not offer; forgets remembered choices (A/B tools)."""
+        return lib().fie_debug_tune_exclude(self.h, (codes or "").encode())
 
     def autotune_report(self):
         buf = ctypes.create_string_buffer(1 << 16)

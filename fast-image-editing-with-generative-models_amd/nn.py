@@ -180,7 +180,7 @@ class _CondNet:
         if not ctx.f32 and te_dim % 64 == 0 and ch0 % 32 == 0 and ch0 <= 512:
             self.te = tuple(_dev(ctx, sd[k]) for k in ("time_embedding.linear_1.weight", "time_embedding.linear_1.bias",
                                                        "time_embedding.linear_2.weight", "time_embedding.linear_2.bias"))
-            self.te_ws = {}                       # per graph slot (ctx.ws_tag): edits in flight must not share the barrier counters
+            self.te_ws = {}                       # per (stream, graph slot): edits in flight must not share the barrier counters
         self.down = []
         for i in range(len(chans)):
             layers = []
@@ -229,8 +229,8 @@ class _CondNet:
         ctx, cfg = self.ctx, self.cfg
         b = pooled.shape[0]
         ad = cfg["addition_time_embed_dim"]
-        add_in = torch.empty((b, cfg["projection_class_embeddings_input_dim"]), device=ctx.device, dtype=ctx.dtype)
-        add_in[:, : pooled.shape[1]] = pooled
+        add_in = ctx._alloc((b, cfg["projection_class_embeddings_input_dim"]))
+        add_in[:, : pooled.shape[1]] = pooled        # a torch copy: begin_image stays OUTSIDE recorded launch programs (hip.Context.record)
         ctx.sinusoid(time_ids, ad, add_in, col0=pooled.shape[1])
         self.add_emb = self.a2(ctx, self.a1(ctx, add_in, act=hip.ACT_SILU))
         for t in self.transformers():
@@ -241,11 +241,13 @@ class _CondNet:
         ctx = self.ctx
         ch0 = self.cfg["block_out_channels"][0]
         if self.te is not None and t_dev.shape[0] <= 4:
-            ws = self.te_ws.get(ctx.ws_tag)
+            ctx.sync_stream()
+            key = (ctx._stream, ctx.ws_tag)       # launches that may run concurrently (other stream, other graph slot) never share the barrier counters
+            ws = self.te_ws.get(key)
             if ws is None:
-                ws = self.te_ws[ctx.ws_tag] = ctx.time_embed_workspace(self.te[0].shape[0])
+                ws = self.te_ws[key] = ctx.time_embed_workspace(self.te[0].shape[0])
             return self.temb_proj(ctx, ctx.time_embed(t_dev, *self.te, ws, add=self.add_emb))
-        s = torch.empty((t_dev.shape[0], ch0), device=ctx.device, dtype=ctx.dtype)
+        s = ctx._alloc((t_dev.shape[0], ch0))
         ctx.sinusoid(t_dev, ch0, s)
         # emb = time_emb + add_emb; resnets consume Linear(SiLU(emb)): add_emb rides in as a per-row bias so the
         # second MLP GEMM's epilogue emits SiLU(emb) directly

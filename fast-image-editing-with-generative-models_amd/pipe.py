@@ -295,7 +295,14 @@ class HipImg2ImgPipeline:
                 if entry is None:
                     if len(self._graphs) >= self.max_graphs:
                         self.eager_overflow += 1
-                        return self.run_device(job)     # cache full: serve this parameter set eagerly (see __init__)
+                        # cache full: serve this parameter set eagerly (see __init__) -- with the SLOT's workspaces (GroupNorm scratch,
+                        # split-K slabs, the timestep-embedding barrier counters are keyed by (stream, ws_tag)): another slot's graph may
+                        # be replaying on its own stream meanwhile
+                        self.ctx.ws_tag = slot
+                        try:
+                            return self.run_device(job)
+                        finally:
+                            self.ctx.ws_tag = 0
                     self._fork_override = fork           # read by _side_stream() during this capture only
                     try:
                         entry = self._capture(key, job, slot)
@@ -418,7 +425,9 @@ class HipImg2ImgPipeline:
         if host is None:
             host = self._host_out[key] = torch.empty(out_u8.shape, dtype=torch.uint8, pin_memory=True)
         host.copy_(out_u8, non_blocking=True)
+        self.ctx.fetch_device_errors()                   # 16 bytes behind the image: a kernel that had to give up does not stay silent
         torch.cuda.current_stream(self.ctx.device).synchronize()
+        self.ctx.check_device_errors(fetch=False)
         return host.numpy().copy()
 
     def _call(self, prompt, negative_prompt, image, control_image, strength, num_inference_steps, guidance_scale,

@@ -30,6 +30,11 @@ extern "C" {
 #define FIE_EHIP (-2)     /* HIP runtime error */
 #define FIE_ENODEV (-3)   /* no gfx950 device */
 
+/* Device-side failures cannot return a code from an asynchronous launch: a kernel that has to give up (today: the bounded spin of the
+ * in-launch barrier of fie_time_embed_f16) stores one of these into the word bound with fie_ctx_error_flag, and the host reads that word
+ * at its next synchronisation (fie_amd: after the D2H copy of every edit; non-zero raises).  The word is sticky until the host clears it. */
+#define FIE_DEVERR_TIME_EMBED_BARRIER 1u
+
 /* epilogue activations (applied to acc + bias [+ rowbias]) */
 #define FIE_ACT_NONE 0
 #define FIE_ACT_SILU 1
@@ -44,6 +49,7 @@ const char* fie_last_error(void);
 /* stream: hipStream_t (0 = default stream).  Replaces: nothing in the reference (torch owns streams there). */
 int fie_ctx_create(int device, void* stream, fie_ctx** out);
 int fie_ctx_set_stream(fie_ctx* ctx, void* stream);
+int fie_ctx_error_flag(fie_ctx* ctx, void* device_word);    /* caller-owned, zero-initialised uint32 in device memory (NULL: none); see FIE_DEVERR_* */
 int fie_ctx_destroy(fie_ctx* ctx);
 
 /* ---- Graph-level entries: the upstream calls they replace are the model forwards inside the diffusers pipeline call
@@ -129,7 +135,9 @@ int fie_sinusoid_f16(fie_ctx* ctx, const float* vals, int B, int nvals, int dim,
  *   t: f32 [B] on the device; W1 [E][C0], W2 [E][E] plain row-major f16 (NOT packed), b1, b2 [E]; add: [B][ld_add] f16 or NULL;
  *   out[b, n] = silu(W2 silu(W1 [cos(t f) | sin(t f)] + b1) + b2 + add[b, n]).  B <= 4, C0 % 32 == 0, E % 64 == 0.
  *   workspace: fie_time_embed_workspace_bytes(E) bytes, ZERO-filled once by the caller (hidden vector + the two counters of the
- *   in-launch barrier between the layers; the kernel leaves the counters at zero).  One workspace per stream / model. */
+ *   in-launch barrier between the layers; the kernel leaves the counters at zero; the third counter word is a sticky "a workgroup's
+ *   bounded spin expired: the output of that launch is not valid" flag, mirrored into the fie_ctx_error_flag word).  One workspace per
+ *   (stream, model): launches that may run concurrently must not share one. */
 int64_t fie_time_embed_workspace_bytes(int E);
 int fie_time_embed_f16(fie_ctx* ctx, const float* t, int B, int C0, int E, const void* W1, const void* b1, const void* W2,
                        const void* b2, const void* add, int64_t ld_add, void* out, int64_t ld_out, void* workspace);
@@ -277,6 +285,7 @@ int fie_splitk_workspace(fie_ctx* ctx, void* workspace, int64_t bytes);
 int fie_debug_splitk(fie_ctx* ctx, int mode);                       /* 0 = never split K, 1 = default */
 int fie_gemm_autotune(fie_ctx* ctx, int on);
 int fie_gemm_autotune_report(fie_ctx* ctx, char* buf, int cap);
+int fie_debug_tune_exclude(fie_ctx* ctx, const char* codes);        /* A/B hook (tools/tuner_ab.py): comma-separated tile codes the tuner must not offer (10000 = every split-K variant; NULL / "" = none); forgets every remembered choice; returns the number of codes parsed */
 int fie_debug_gemm_probe(fie_ctx* ctx, int mode);                  /* TIMING-ONLY probes of the LDS-DMA kernels (outputs are wrong): 0 off, 1 = DMA loads dropped by the descriptor, 2 = every tile loads tile (0,0), 3 = ring kernels: no DMA issued in the K loop, 4 = no epilogue */
 int fie_debug_gemm_stamps(fie_ctx* ctx, void* buf);                  /* device buffer for the stamped ring kernels (tile codes 97 / 98): per tile and wave 8 uint32 cycle sums -- [0] drain + barrier, [1]/[4] DMA issue, [2]/[5] fragment reads, [3]/[6] MFMA issue (code 98: [0] = whole K-steps); NULL detaches */
 const char* fie_debug_last_gemm_kernel(fie_ctx* ctx);              /* kernel / tile of the last fie_gemm_f16 / fie_conv3x3_nhwc_f16 launch */

@@ -288,6 +288,35 @@ def test_gemm_conv_every_shipped_kernel(fie, code):
             fie.force_tile(0)
 
 
+def test_ring_256x320_tile_gemm_view(fie):
+    """Tile code 63 (256x320, 8 waves, wave tile 128x80, two-stage ring): the exact-fit tile of the FF1 projection (M 2048 x N 10240:
+    256 tiles = one per CU).  GEGLU at the real shape, ragged M / N / K with bias + row bias + SiLU + scale + in-place residual, the
+    [A1 | A2] column concatenation, against fp32 torch; the conv view refuses the code loudly."""
+    from fie_amd import hip
+    try:
+        fie.force_tile(63)
+        a, w, b = rnd(2048, 1280, seed=1), rnd(10240, 1280, seed=2, scale=1280 ** -0.5), rnd(10240, seed=3)
+        out = fie.gemm(a.to(DEV), fie.pack_linear(w.to(DEV), geglu=True), 10240, act=hip.ACT_GEGLU,
+                       bias=torch.stack([b[:5120], b[5120:]], 1).reshape(-1).contiguous().to(DEV))
+        assert "256x320" in hip.last_gemm_kernel(fie)
+        full = a.float() @ w.float().T + b.float()
+        assert rel_err(out, full[:, :5120] * F.gelu(full[:, 5120:])) < 3e-3
+        for m, n, k in [(1000, 640, 200), (300, 328, 72), (2048, 1280, 5120), (77, 960, 2048)]:
+            a, w, bias, res, rb = rnd(m, k, seed=m), rnd(n, k, seed=n, scale=k ** -0.5), rnd(n, seed=3), rnd(m, n, seed=4), rnd(2, n, seed=5)
+            inplace = res.to(DEV).clone()
+            out = fie.gemm(a.to(DEV), fie.pack_linear(w.to(DEV)), n, bias=bias.to(DEV), rowbias=rb.to(DEV), rows_per_batch=(m + 1) // 2,
+                           residual=inplace, out=inplace, scale=0.5, act=hip.ACT_SILU)
+            ref = a.float() @ w.float().T + bias.float() + rb.float().repeat_interleave((m + 1) // 2, 0)[:m]
+            assert rel_err(out, F.silu(ref) * 0.5 + res.float()) < 3e-3, (m, n, k)
+        a1, a2, w = rnd(700, 128, seed=4), rnd(700, 192, seed=5), rnd(320, 320, seed=6, scale=320 ** -0.5)
+        out = fie.gemm(a1.to(DEV), fie.pack_linear(w.to(DEV)), 320, a2=a2.to(DEV))
+        assert rel_err(out, torch.cat([a1, a2], 1).float() @ w.float().T) < 3e-3
+        with pytest.raises(hip.FieError, match="GEMM view only"):
+            fie.conv3x3(rnd(1, 16, 16, 64, seed=7).to(DEV), fie.pack_conv3x3(rnd(64, 64, 3, 3, seed=8).to(DEV)), 64)
+    finally:
+        fie.force_tile(0)
+
+
 def test_phased_256x256_kernel_large_and_odd_ktiles(fie):
     """gemm8_kernel (tile code 81) at the sizes it is selected for, against the ring kernel and fp32 torch: K-tile counts 1, 2,
     3 (odd: the buffer-parity tail), 20 and 64; epilogues (bias, row bias, SiLU, GEGLU, scale + residual); conv with tap
@@ -503,7 +532,9 @@ def test_split_k_in_launch_reduction(fie):
         # GEGLU (FF1-type) and ragged M / N / K tails
         fie.force_tile(30096)
         a, wg, bg = rnd(1000, 1288, seed=11), rnd(520, 1288, seed=12, scale=1288 ** -0.5), rnd(520, seed=13)
-        out = fie.gemm(a.to(DEV), fie.pack_linear(wg.to(DEV), geglu=True), 520, bias=bg.to(DEV), act=hip.ACT_GEGLU)
+        out = fie.gemm(a.to(DEV), fie.pack_linear(wg.to(DEV), geglu=True), 520, act=hip.ACT_GEGLU,
+                       bias=torch.stack([bg[:260], bg[260:]], 1).reshape(-1).contiguous().to(DEV))        # (value, gate) interleaved like the rows
+        assert "split-K 3" in hip.last_gemm_kernel(fie)
         full = a.float() @ wg.float().T + bg.float()
         assert rel_err(out, full[:, :260] * F.gelu(full[:, 260:])) < 3e-3
         # repeats on one workspace with changing inputs; a second stream splitting on its own workspace meanwhile
@@ -596,6 +627,23 @@ def test_groupnorm_statistics_from_the_producing_conv(fie, cout, code):
     o4._gn_tag = o._gn_tag
     assert o._gn_tag is not None
     assert rel_err(fie.groupnorm(o4, gamma, beta, groups, 1e-6, False), fie.groupnorm(o4.clone(), gamma, beta, groups, 1e-6, False).float()) < 1e-3
+
+
+def test_gn_stats_target_is_disarmed_by_a_failing_call(fie):
+    """ADVICE r2 (gemm_conv.hip:831): the one-shot GroupNorm target is taken at the top of every GEMM / conv entry, so a call that fails
+    its argument checks does not leave it armed for the next, unrelated launch."""
+    from fie_amd import hip
+    lib = hip.lib()
+    buf = torch.full((1 << 16,), 7.0, device=DEV)
+    a, w = rnd(256, 128, seed=1).to(DEV), fie.pack_linear(rnd(128, 128, seed=2, scale=128 ** -0.5).to(DEV))
+    out = torch.empty(256, 128, device=DEV, dtype=torch.float16)
+    assert lib.fie_gn_stats_target(fie.h, buf.data_ptr(), 64, 32) == 0
+    rc = lib.fie_gemm_f16(fie.h, a.data_ptr(), 128, 128, None, 0, w.data_ptr(), w.stride(0), out.data_ptr(), 128, 256, 128, 124, None, None, 0, 0,
+                          None, 0, 1.0, 0)                           # K = 124: not a multiple of 8 -> FIE_EINVAL
+    assert rc != 0
+    fie.gemm(a, w, 128, out=out)                                  # must NOT write GroupNorm sums anywhere
+    torch.cuda.synchronize()
+    assert bool((buf == 7.0).all())
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,code", [(2, 16, 16, 128, 128, 0), (1, 24, 40, 64, 256, 54), (2, 32, 32, 256, 512, 81), (1, 20, 12, 128, 192, 42)])

@@ -321,6 +321,46 @@ def test_graph_cache_is_bounded_and_entries_keep_their_own_latents(rig):
         pipe.max_graphs, pipe.use_graph = old[0], old[1]
 
 
+def test_overflow_on_slot_1_beside_a_replaying_slot_0(rig):
+    """ADVICE r2 (pipe.py:297): a full graph cache serves a call eagerly; on slot 1 that eager run must use slot 1's workspaces
+    (GroupNorm scratch, split-K slabs, the timestep-embedding barrier counters are keyed by (stream, graph slot)) while slot 0's graph
+    replays on its own stream.  Worker threads as in `run_batch.py --in_flight 2`; results must equal the graphed ones."""
+    from concurrent.futures import ThreadPoolExecutor
+    cfgs, sds32, pipe = rig
+    img = synth_image(29, 128)
+    ctrl = Image.fromarray(np.zeros((128, 128, 3), np.uint8))
+    call = lambda g, slot: np.asarray(pipe(prompt="a [toy]", image=img, control_image=ctrl, strength=0.5, guidance_scale=g, slot=slot,
+                                           generator=torch.Generator("cpu").manual_seed(3), output_type="np").images[0])
+    old = pipe.max_graphs, pipe.use_graph, pipe.eager_overflow
+    try:
+        pipe.use_graph = True
+        ref0, ref1 = call(1.62, 0), call(1.77, 0)                 # graphed on slot 0 (the second key only as the reference image)
+        pipe.max_graphs = len(pipe._graphs)                       # full: slot 1 overflows into the eager path
+        outs = {}
+
+        def work(slot):
+            for _ in range(3):
+                outs.setdefault(slot, []).append(call(1.62, 0) if slot == 0 else call(1.77, 1))
+
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            list(pool.map(work, range(2)))
+        assert pipe.eager_overflow >= old[2] + 3 and pipe.ctx.ws_tag == 0
+        assert all(np.array_equal(o, ref0) for o in outs[0]) and all(np.array_equal(o, ref1) for o in outs[1])
+    finally:
+        pipe.max_graphs, pipe.use_graph = old[0], old[1]
+
+
+def test_device_error_word_reaches_the_host(fie):
+    """include/fie.h FIE_DEVERR_*: a kernel that has to give up (the bounded spin of the timestep-embedding barrier) sets the context's
+    device error word; the host reads it behind every edit's D2H copy and raises.  The word is set by hand here."""
+    from fie_amd import hip
+    fie.check_device_errors()
+    fie._err[0] = 1
+    with pytest.raises(hip.FieError, match="barrier timed out"):
+        fie.check_device_errors()
+    fie.check_device_errors()                                     # cleared
+
+
 def test_editor_from_a_weights_directory_whose_topology_matches_no_preset(fie, tmp_path):
     """FastEditor(weights_dir=...) builds its graphs from the directory's config.json files (default ctor flags: ssd-1b would
     otherwise pick the guessed 'small' ControlNet preset) and matches the oracle run on the same files."""
