@@ -192,13 +192,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 
 template <int D, int QF, int KT>
 int launch_attn(fie_ctx* ctx, const AttnArgs& a, int B) {
-    const size_t lds = (size_t)2 * KT * D * sizeof(half_t);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QF, KT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    const size_t lds = (size_t)2 * KT * D * sizeof(half_t);      // function attribute (dynamic LDS limit): fie_attn_init
     const dim3 grid((unsigned)((a.Tq + 64 * QF - 1) / (64 * QF)), (unsigned)a.H, (unsigned)B), block(256);
     fie_launch(ctx, (attn_kernel<D, QF, KT>), grid, block, lds, a);
     FIE_LAUNCH_CHECK();
@@ -459,21 +453,31 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
 template <int D, int QF, int KT>
 int launch_attn2(fie_ctx* ctx, const AttnArgs& a, int B) {
     const size_t lds = (size_t)4 * KT * D * sizeof(half_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<D, QF, KT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     const dim3 grid((unsigned)((a.Tq + 64 * QF - 1) / (64 * QF)), (unsigned)a.H, (unsigned)B), block(256);
     fie_launch(ctx, (attn2_kernel<D, QF, KT>), grid, block, lds, a);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
 
-int g_attn_variant = 0;   // tuning hook: 0 = v2 (LDS-DMA ring, deferred rescale), 1 = v1, 2 / 3 = v2 with 128 / 64 queries per block forced
+template <int D, int QF, int KT>
+hipError_t attn_attrs() {      // dynamic-LDS limits of both kernel generations, once per device (fie_ctx_create), never on the launch path
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QF, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KT * D * (int)sizeof(half_t));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<D, QF, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KT * D * (int)sizeof(half_t));
+    return e;
+}
 
 }  // namespace
+
+int fie_attn_init(void) {
+    hipError_t e = attn_attrs<512, 1, 32>();
+    if (e == hipSuccess) e = attn_attrs<64, 2, 64>();
+    if (e == hipSuccess) e = attn_attrs<64, 1, 64>();
+    if (e != hipSuccess) {
+        fie_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return FIE_EHIP;
+    }
+    return FIE_OK;
+}
 
 extern "C" int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V,
                                  int64_t ldv, void* O, int64_t ldo, int B, int H, int Tq, int Tk, int D, float scale,
@@ -490,19 +494,20 @@ extern "C" int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const
     a.scale_log2 = scale * 1.4426950408889634f;
     FIE_DESC(ctx, "attn B=%d H=%d Tq=%d Tk=%d D=%d flop=%.0f", B, H, Tq, Tk, D, 4.0 * B * H * Tq * Tk * D);
     const int64_t blocks128 = (int64_t)((Tq + 127) / 128) * H * B;
-    if (g_attn_variant == 1) {
+    if (ctx->attn_variant == 1) {
         if (D == 512) return launch_attn<512, 1, 32>(ctx, a, B);
         if (blocks128 >= ctx->num_cus * 2) return launch_attn<64, 2, 64>(ctx, a, B);
         return launch_attn<64, 1, 64>(ctx, a, B);
     }
     if (D == 512) return launch_attn2<512, 1, 32>(ctx, a, B);
-    if (g_attn_variant == 2) return launch_attn2<64, 2, 64>(ctx, a, B);      // A/B: 128 queries per block everywhere
-    if (g_attn_variant == 3) return launch_attn2<64, 1, 64>(ctx, a, B);      // A/B: 64 queries per block everywhere
+    if (ctx->attn_variant == 2) return launch_attn2<64, 2, 64>(ctx, a, B);      // A/B: 128 queries per block everywhere
+    if (ctx->attn_variant == 3) return launch_attn2<64, 1, 64>(ctx, a, B);      // A/B: 64 queries per block everywhere
     if (blocks128 >= ctx->num_cus * 2) return launch_attn2<64, 2, 64>(ctx, a, B);
     return launch_attn2<64, 1, 64>(ctx, a, B);
 }
 
-extern "C" int fie_debug_attn_variant(int v) {
-    g_attn_variant = v;
+extern "C" int fie_debug_attn_variant(fie_ctx* ctx, int v) {
+    FIE_REQUIRE(ctx != nullptr && v >= 0 && v <= 3, "fie_debug_attn_variant: bad argument");
+    ctx->attn_variant = v;
     return FIE_OK;
 }

@@ -7,6 +7,7 @@
 int fie_gemm_init(void);
 int fie_gemm8_init(void);
 int fie_gemm_w8_init(void);
+int fie_attn_init(void);
 
 static thread_local char g_err[512] = "";
 
@@ -87,6 +88,7 @@ int fie_ctx_create(int device, void* stream, fie_ctx** out) {
     int rc = fie_gemm_init();
     if (rc == FIE_OK) rc = fie_gemm8_init();
     if (rc == FIE_OK) rc = fie_gemm_w8_init();
+    if (rc == FIE_OK) rc = fie_attn_init();
     (void)hipSetDevice(cur);
     if (rc != FIE_OK) return rc;
     fie_ctx* c = new fie_ctx();

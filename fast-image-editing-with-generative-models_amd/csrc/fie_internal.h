@@ -54,6 +54,7 @@ struct fie_ctx {
     float* gn_target = nullptr;              // fie_gn_stats_target: consumed by the next GEMM / conv launch
     int64_t gn_target_rows = 0;
     int gn_target_groups = 0;
+    int attn_variant = 0;                    // fie_debug_attn_variant: 0 = v2 (LDS-DMA ring, deferred rescale), 1 = v1, 2 / 3 = v2 with 128 / 64 queries per block forced
     int gn_onepass = 1;                      // fie_debug_gn_onepass: 0 = always the three-kernel GroupNorm
     unsigned* err_flag = nullptr;            // fie_ctx_error_flag: device word kernels set to a FIE_DEVERR_* code instead of failing silently
     void* sk_ws = nullptr;                   // fie_splitk_workspace: [4096 arrival counters (zero between launches)][fp32 partial-tile slabs]

@@ -72,7 +72,7 @@ SIGNATURES = {
     "fie_canny_rgb_device_u8": [_P, _P, _I, _I, _I, _I, _P, _P, _c.POINTER(_I)],
     "fie_resize_rgb_u8": [_P, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P, _I, _P],
     "fie_debug_force_tile": [_P, _I],
-    "fie_debug_attn_variant": [_I],
+    "fie_debug_attn_variant": [_P, _I],
     "fie_debug_gn_onepass": [_P, _I],
     "fie_debug_tile_override": [_P, _c.c_char_p],
     "fie_debug_last_gemm_kernel": [_P],

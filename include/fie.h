@@ -58,10 +58,15 @@ int fie_ctx_destroy(fie_ctx* ctx);
  *
  * Mechanism: LAUNCH PROGRAMS.  The host walks a graph once, with the device buffers it will keep using (weights, static
  * input / output / scratch tensors), between fie_program_begin and fie_program_end: every kernel launch the op entries below
- * issue meanwhile is appended to the program (kernel, grid, block, LDS bytes, argument values) while still executing.
+ * issue meanwhile EXECUTES as usual and is ALSO appended to the program (kernel, grid, block, LDS bytes, argument values).
  * fie_program_run re-issues the whole list on the ctx stream from C++: no host-side shape logic, no Python, asynchronous and
  * hipGraph-capturable like any single op.  New inputs = new CONTENTS of the same input buffers.  The caller keeps every buffer
  * the program references alive and destroys programs it created.
+ * What these entries are NOT: a C++ implementation of the model graphs.  The graph logic (which layer follows which, the shapes, the
+ * weight packing) lives in the Python host code (fie_amd/nn.py, vae.py, clip.py); a named entry is a REPLAY HANDLE for a launch list that
+ * walk recorded, with every pointer frozen in.  A non-Python host therefore cannot reach fie_unet_forward without first driving the op
+ * entries below in graph order itself (there is no fie_weights_register: the op entries take weight pointers per call).  The product
+ * path (hipGraph replay of the Python walk) does not go through these entries; tests/test_programs_gpu.py does.
  *   fie_graph_register binds a program to one of the names "unet_forward", "controlnet_forward", "vae_encode", "vae_decode",
  *   "clip_text_forward"; the five named entries run the program bound to their name (FIE_EINVAL if none). */
 typedef struct fie_program fie_program;
@@ -292,7 +297,7 @@ const char* fie_debug_last_gemm_kernel(fie_ctx* ctx);              /* kernel / t
 int fie_debug_oplog(fie_ctx* ctx, int on);                         /* launch log for the per-shape profile (tools/shape_profile.py): while on, every launch appends "kernel symbol|blocks|threads|LDS bytes|op description (shape, tile code, algorithmic flop / bytes)" */
 int fie_debug_oplog_mark(fie_ctx* ctx, const char* text);           /* appends "#text" (a stage boundary) when the log is on */
 int64_t fie_debug_oplog_read(fie_ctx* ctx, char* buf, int64_t cap);  /* newline-joined log into buf when it fits; returns its length (cap 0: size query) */
-int fie_debug_attn_variant(int variant);   /* 0 = default kernel, 1 = first-generation kernel (A/B benchmarking) */
+int fie_debug_attn_variant(fie_ctx* ctx, int variant);   /* per context; 0 = default kernel, 1 = first-generation kernel, 2 / 3 = 128 / 64 queries per block forced (A/B benchmarking) */
 int fie_debug_gn_onepass(fie_ctx* ctx, int enable);      /* per context; 1 = default (single-pass GroupNorm on small maps), 0 = always partial/finalize/apply */
 
 /* ---- K11 Canny on the host (integer exact).  Replaces cv2.cvtColor(RGB2GRAY) + cv2.Canny at

@@ -12,6 +12,7 @@ from src.pipeline import FastEditor  # noqa: E402
 
 ed = FastEditor(model_name="ssd-1b", use_full_controlnet=True, enable_cpu_offload=False)
 pipe = ed.pipe
+ctx = pipe.ctx
 img = synth_item_image(3).resize((1024, 1024))
 ctrl = ed.preprocess_image(img)
 job = pipe.prepare("a photo of a [red] house", "", img, ctrl, 0.5, 4, 1.5, 0.5, torch.Generator().manual_seed(42))
@@ -20,7 +21,7 @@ torch.cuda.synchronize()
 for rnd in range(3):
     row = []
     for v in (0, 2, 3):
-        hip.lib().fie_debug_attn_variant(v)
+        hip.lib().fie_debug_attn_variant(ctx.h, v)
         row.append(f"variant {v}: {min(time_unet_forward(pipe, job, iters=4) for _ in range(2)):.3f} ms")
     print("  ".join(row), flush=True)
-hip.lib().fie_debug_attn_variant(0)
+hip.lib().fie_debug_attn_variant(ctx.h, 0)

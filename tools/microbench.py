@@ -91,7 +91,7 @@ def run(which, tiles):
             v = torch.randn(b * tk, c, device=DEV, dtype=torch.float16)
             res = []
             for var in (1, 0):
-                hip.lib().fie_debug_attn_variant(var)
+                hip.lib().fie_debug_attn_variant(ctx.h, var)
                 dt = timeit(lambda: ctx.attention(q, k, v, hn, d, tq, tk, b), iters=10)
                 res.append(f"v{2 - var}: {dt * 1e6:8.1f} us {4 * b * hn * tq * tk * d / dt / 1e12:7.1f} TF")
             print(f"attn B={b} H={hn} Tq={tq} Tk={tk} D={d}: " + "  ".join(res), flush=True)
