@@ -22,6 +22,7 @@ struct AttnArgs {
     int H, Tq, Tk;
     float scale_log2;
     int causal;
+    float o8_inv;      // > 0 (attn2_kernel only): O is e4m3 bytes, value * o8_inv saturated to +-448, ldo in bytes (fie_attention_f16_o8)
 };
 
 template <int D>
@@ -439,6 +440,20 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         const int q = q0 + a * 16 + fr;
         if (q >= p.Tq) continue;
+        if (p.o8_inv > 0.f) {                               // e4m3 output for an fp8-activation out-projection: 4 bytes per lane and fragment
+            unsigned char* orow8 = reinterpret_cast<unsigned char*>(p.O) + ((int64_t)b * p.Tq + q) * p.ldo + h * D;
+            const float s8 = inv * p.o8_inv;
+#pragma unroll
+            for (int d = 0; d < DF; ++d) {
+                float x[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = fminf(fmaxf(o[a][d][r] * s8, -448.f), 448.f);
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], pk, true);
+                *reinterpret_cast<int*>(orow8 + d * 16 + fq * 4) = pk;
+            }
+            continue;
+        }
         half_t* orow = p.O + ((int64_t)b * p.Tq + q) * p.ldo + h * D;
 #pragma unroll
         for (int d = 0; d < DF; ++d) {
@@ -479,9 +494,8 @@ int fie_attn_init(void) {
     return FIE_OK;
 }
 
-extern "C" int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V,
-                                 int64_t ldv, void* O, int64_t ldo, int B, int H, int Tq, int Tk, int D, float scale,
-                                 int causal) {
+static int attention_impl(fie_ctx* ctx, const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O, int64_t ldo, int B, int H,
+                          int Tq, int Tk, int D, float scale, int causal, float o8_inv) {
     FIE_REQUIRE(ctx && Q && K && V && O, "fie_attention_f16: NULL argument");
     FIE_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "fie_attention_f16: bad shape");
     FIE_REQUIRE(D == 64 || D == 512, "fie_attention_f16: head dim %d not built (64, 512)", D);
@@ -492,6 +506,8 @@ extern "C" int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const
     a.Q = (const half_t*)Q; a.ldq = ldq; a.K = (const half_t*)K; a.ldk = ldk; a.V = (const half_t*)V; a.ldv = ldv;
     a.O = (half_t*)O; a.ldo = ldo; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
     a.scale_log2 = scale * 1.4426950408889634f;
+    a.o8_inv = o8_inv;
+    FIE_REQUIRE(o8_inv == 0.f || (ctx->attn_variant != 1 && D == 64), "fie_attention_f16_o8: e4m3 output is built into the d = 64 kernel only");
     FIE_DESC(ctx, "attn B=%d H=%d Tq=%d Tk=%d D=%d flop=%.0f", B, H, Tq, Tk, D, 4.0 * B * H * Tq * Tk * D);
     const int64_t blocks128 = (int64_t)((Tq + 127) / 128) * H * B;
     if (ctx->attn_variant == 1) {
@@ -504,6 +520,20 @@ extern "C" int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const
     if (ctx->attn_variant == 3) return launch_attn2<64, 1, 64>(ctx, a, B);      // A/B: 64 queries per block everywhere
     if (blocks128 >= ctx->num_cus * 2) return launch_attn2<64, 2, 64>(ctx, a, B);
     return launch_attn2<64, 1, 64>(ctx, a, B);
+}
+
+extern "C" int fie_attention_f16(fie_ctx* ctx, const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V,
+                                 int64_t ldv, void* O, int64_t ldo, int B, int H, int Tq, int Tk, int D, float scale,
+                                 int causal) {
+    return attention_impl(ctx, Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Tq, Tk, D, scale, causal, 0.f);
+}
+
+// The same attention with an e4m3 output (BASELINE config 5: the attention out-projections read fp8 activations): O8 [B * Tq, H * D] bytes,
+// row stride ldo8 BYTES, value * inv_scale saturated to the e4m3 range.  d = 64 only.
+extern "C" int fie_attention_f16_o8(fie_ctx* ctx, const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O8,
+                                    int64_t ldo8, int B, int H, int Tq, int Tk, int D, float scale, int causal, float inv_scale) {
+    FIE_REQUIRE(inv_scale > 0.f, "fie_attention_f16_o8: inv_scale must be positive");
+    return attention_impl(ctx, Q, ldq, K, ldk, V, ldv, O8, ldo8, B, H, Tq, Tk, D, scale, causal, inv_scale);
 }
 
 extern "C" int fie_debug_attn_variant(fie_ctx* ctx, int v) {

@@ -45,6 +45,10 @@ struct GemmArgs {
     // writes its fp32 partial tile to sk_slabs[tile][slice] (write-through), draws a ticket from sk_tickets[tile]; the block that draws the last
     // ticket sums the slices IN SLICE ORDER (deterministic) and runs the epilogue.  splitk <= 1: off
     int splitk; float* sk_slabs; unsigned* sk_tickets;
+    // fp8 activations (gemm_x8.hip, BASELINE config 5): a_scale = dequantisation scale of the e4m3 A operand (0 = none; multiplies the accumulator
+    // together with w_scale); out_f8 = the output is written as e4m3 bytes, value * out_inv_scale, saturated to +-448 (C then points at bytes and
+    // ldc counts bytes): the consumer GEMM reads it without any conversion
+    float a_scale; int out_f8; float out_inv_scale;
     int order;                              // 0: n-tiles fastest (an XCD owns a range of rows), 1: m-tiles fastest (an XCD owns a range of columns)
 };
 
@@ -104,9 +108,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
     auto as_h4 = [](u32x2 v) { f16x4 h; __builtin_memcpy(&h, &v, 8); return h; };
 
     if (p.w_scale) {
+        const float as = p.a_scale != 0.f ? p.a_scale : 1.f;
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
-            const float4 ws = *reinterpret_cast<const float4*>(p.w_scale + col(i));
+            float4 ws = *reinterpret_cast<const float4*>(p.w_scale + col(i));
+            ws.x *= as; ws.y *= as; ws.z *= as; ws.w *= as;
 #pragma unroll
             for (int j = 0; j < FM; ++j) { acc[i][j][0] *= ws.x; acc[i][j][1] *= ws.y; acc[i][j][2] *= ws.z; acc[i][j][3] *= ws.w; }
         }
@@ -224,6 +230,31 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
                     *dst = make_float2(vs, vq);
                 }
             }
+        }
+    }
+    if constexpr (BUF) {
+        if (p.out_f8) {                                     // e4m3 bytes for an fp8-activation consumer: 4 (GEGLU: 2) bytes per lane and fragment
+            const __amdgpu_buffer_rsrc_t rs8 = rsrc(p.C, (int64_t)(p.M - 1) * p.ldc + (geglu ? p.N >> 1 : p.N));
+            const float inv = p.out_inv_scale;
+            auto q = [&](float x) { return fminf(fmaxf(x * inv, -448.f), 448.f); };
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const int m = mrow + j * 16;
+                const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldc : kRowOut;
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    const int n = ncol + i * 16;
+                    if (geglu) {
+                        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q(acc[i][j][0]), q(acc[i][j][1]), 0, false);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pk & 0xffff), rs8, ro + (n < p.N ? (unsigned)(n >> 1) : kColOut), 0, 0);
+                    } else {
+                        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q(acc[i][j][0]), q(acc[i][j][1]), 0, false);
+                        pk = __builtin_amdgcn_cvt_pk_fp8_f32(q(acc[i][j][2]), q(acc[i][j][3]), pk, true);
+                        __builtin_amdgcn_raw_buffer_store_b32((unsigned)pk, rs8, ro + (n < p.N ? (unsigned)n : kColOut), 0, 0);
+                    }
+                }
+            }
+            return;
         }
     }
     // ---- stores: lane holds C[m = .. + fr][n = .. + fq*4 + (0..3)]
@@ -347,3 +378,6 @@ int fie_gemm_init(void);           // same for the kernels of gemm_conv.hip
 // gemm_w8.hip: fp8-weight ring kernels; code 62 = 256x128 (8 waves), 42 = 128x64, 43 = 64x64
 int fie_launch_gemm_w8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int conv, int code);
 int fie_gemm_w8_init(void);
+// gemm_x8.hip: e4m3 activations x e4m3 weights on the block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales), GEMM view only
+int fie_launch_gemm_x8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int code);
+int fie_gemm_x8_init(void);

@@ -529,9 +529,9 @@ constexpr int64_t kSkTickets = 4096;        // arrival counters at the head of t
 // slice, counters and slabs inside the bound workspace.  Returns 1 when split-K cannot run.
 inline int splitk_fit(const fie_ctx* ctx, const GemmArgs& a, int code, int bm, int bn, int want) {
     const bool ring = (code >= 42 && code <= 54) || code == 62 || code == 95 || code == 96;
-    if (want <= 1 || !ring || !ctx->sk_ws || !ctx->splitk_mode || a.w_scale) return 1;
+    if (want <= 1 || !ring || !ctx->sk_ws || !ctx->splitk_mode || (a.w_scale && a.a_scale == 0.f)) return 1;
     const int64_t tiles = (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (a.oscat == 2 ? 4 : 1);
-    const int nk = (a.K + BK - 1) / BK;
+    const int nk = (a.K + BK - 1) / BK / (a.a_scale != 0.f ? 2 : 1);      // fp8 activations: 128 k-values per K-step
     int s = want;
     while (s > 1 && (nk / s < 4 || tiles > kSkTickets || (int64_t)(kSkTickets * 4 + tiles * s * bm * bn * 4) > ctx->sk_bytes)) --s;
     return s;
@@ -561,7 +561,14 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
         };
         order = fabric(nbm, nbn, a_tile, w_tile) < fabric(nbn, nbm, w_tile, a_tile) ? 1 : 0;
     }
-    if (a.w_scale) {                 // fp8 weights: the three W8 ring tiles (gemm_w8.hip)
+    const bool x8 = a.w_scale && a.a_scale != 0.f;           // e4m3 activations x e4m3 weights (gemm_x8.hip): its own tile set
+    if (x8) {
+        FIE_REQUIRE(dma_ok && MODE == 0, "fp8 activations: GEMM view on the LDS-DMA kernels only");
+        code = code == 96 || code == 81 || code == 61 ? 62 : code == 95 ? 51 : code == 44 || code == 2 ? 42 : code == 46 || code == 3 || code == 1 ? 43 : code;
+        FIE_REQUIRE(code == 42 || code == 43 || code == 47 || code == 51 || code == 52 || code == 54 || code == 62 || code == 63, "tile code %d has no fp8-activation kernel", code);
+        for (const TileDim& d : kTiles)
+            if (d.code == code) t = &d;
+    } else if (a.w_scale) {          // fp8 weights: the three W8 ring tiles (gemm_w8.hip)
         FIE_REQUIRE(dma_ok, "fp8 weights: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)");
         code = (code == 43 || code == 46 || code == 3) ? 43 : (code == 42 || code == 44 || code == 2) ? 42 : (code == 52 || code == 54) ? code : 62;
         for (const TileDim& d : kTiles)
@@ -583,7 +590,12 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
         FIE_DESC(ctx, "conv M=%d N=%d K=%d in=%dx%dx%d s%d u%d%s%s code=%d flop=%.0f", a.M * (a.oscat == 2 ? 4 : 1), a.N, a.K, a.H, a.W, a.Cin, a.stride, a.ups,
                  a.taps2 ? " up2x-parity" : "", a.A2 ? " +1x1" : "", code + 10000 * (split > 1 ? split : 0), 2.0 * a.M * a.N * a.K * (a.oscat == 2 ? 4 : 1));
     else
-        FIE_DESC(ctx, "gemm M=%d N=%d K=%d act=%d%s%s code=%d flop=%.0f", a.M, a.N, a.K, a.act, a.res ? " +res" : "", a.w_scale ? " w8" : "", code + 10000 * (split > 1 ? split : 0), 2.0 * a.M * a.N * a.K);
+        FIE_DESC(ctx, "gemm M=%d N=%d K=%d act=%d%s%s code=%d flop=%.0f", a.M, a.N, a.K, a.act, a.res ? " +res" : "", a.w_scale ? (a.a_scale != 0.f ? " a8w8" : " w8") : "", code + 10000 * (split > 1 ? split : 0), 2.0 * a.M * a.N * a.K);
+    if (x8) {
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "gemm3x8_kernel<%dx%d> (gemm, fp8 activations x fp8 weights, tile code %d%s", t->bm, t->bn, code, split > 1 ? "" : ")");
+        if (split > 1) snprintf(ctx->last_kernel + strlen(ctx->last_kernel), 24, ", split-K %d)", split);
+        return fie_launch_gemm_x8(ctx, a, code);
+    }
     if (a.w_scale) {
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "gemm3w8_kernel<%dx%d> (%s, fp8 weights, tile code %d)", t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
         return fie_launch_gemm_w8(ctx, a, MODE == 1, code);
@@ -637,6 +649,7 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81, 63, 47};      // 47 (128x96): FIE_TUNE_47=0 leaves it out
     static const bool use47 = !(getenv("FIE_TUNE_47") && getenv("FIE_TUNE_47")[0] == '0');
     static const int kW8[] = {43, 42, 62, 52, 54};
+    static const int kX8[] = {43, 42, 47, 51, 52, 54, 62, 63};
     const size_t bytes = (size_t)a.M * (a.oscat ? 4 : 1) * (size_t)a.ldc * sizeof(half_t);     // a parity conv scatters its M rows over 4 M output rows
     if (bytes > ctx->tune_bytes) {
         if (ctx->tune_buf) (void)hipFree(ctx->tune_buf);
@@ -672,8 +685,9 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     if (verbose) fprintf(stderr, "[fie tune] %s M=%d N=%d K=%d: rule %d %.1f us", MODE == 1 ? "conv" : "gemm", a.M, a.N, a.K, guess, t_guess * 1e3f);
     int best = guess;
     float t_best = t_guess * 0.97f;                          // a challenger has to win by 3 %
-    const int* cand = a.w_scale ? kW8 : kRing;
-    const int ncand = a.w_scale ? 5 : use47 ? 11 : 10;
+    const bool x8 = a.w_scale && a.a_scale != 0.f;
+    const int* cand = x8 ? kX8 : a.w_scale ? kW8 : kRing;
+    const int ncand = x8 ? 8 : a.w_scale ? 5 : use47 ? 11 : 10;
     auto excluded = [&](int c) {
         for (int e : ctx->tune_exclude)
             if (e == c) return e != 0;
@@ -685,6 +699,7 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
         if ((c == 43 || c == 46) && blocks(64, 64) > 64 * ctx->num_cus) continue;       // tens of thousands of tiny tiles: never wins
         if ((c == 81 || c == 96 || c == 62) && 2 * blocks(256, 128) < ctx->num_cus) continue;
         if (c == 63 && (MODE != 0 || a.N % 320 != 0 || 2 * blocks(256, 320) < ctx->num_cus)) continue;
+        if (x8 && (c == 62 || c == 51) && 2 * blocks(c == 62 ? 256 : 128, 128) < ctx->num_cus) continue;
         if (c == 81 && MODE == 1 && a.A2) continue;            // side inputs: ring kernels only
         const float tc = time_of(c);
         if (verbose) fprintf(stderr, ", %d %.1f", c, tc * 1e3f);
@@ -693,9 +708,13 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     // split-K: big tiles whose grid leaves CUs idle (the M = 2048 class: 80 tiles of 256x128 on 256 CUs) with the K-steps of a tile dealt
     // to 2-4 blocks, reduced in the launch (gemm_common.h: splitk_reduce).  Changes the fp32 summation order, so unlike the tile choice
     // it is visible in the last bit of some f16 outputs; fixed per (shape, choice), hence deterministic within a process.
-    if (!a.w_scale && ctx->sk_ws && ctx->splitk_mode && !excluded(10000)) {
-        static const struct { int code, bm, bn, per_cu; } kSplit[] = {{96, 256, 128, 1}, {95, 128, 128, 1}, {47, 128, 96, 1}, {54, 192, 128, 2}, {52, 128, 128, 2}};
-        for (const auto& c : kSplit) {
+    if ((!a.w_scale || x8) && ctx->sk_ws && ctx->splitk_mode && !excluded(10000)) {
+        struct SplitCand { int code, bm, bn, per_cu; };
+        static const SplitCand kSplitF16[] = {{96, 256, 128, 1}, {95, 128, 128, 1}, {47, 128, 96, 1}, {54, 192, 128, 2}, {52, 128, 128, 2}};
+        static const SplitCand kSplitX8[] = {{62, 256, 128, 1}, {51, 128, 128, 1}, {47, 128, 96, 1}, {54, 192, 128, 2}, {52, 128, 128, 2}};
+        const SplitCand* sc = x8 ? kSplitX8 : kSplitF16;
+        for (int ci = 0; ci < 5; ++ci) {
+            const SplitCand& c = sc[ci];
             if (excluded(c.code)) continue;
             const int64_t nb = blocks(c.bm, c.bn) * (a.oscat == 2 ? 4 : 1);
             if (nb >= ctx->num_cus * c.per_cu) continue;                 // the grid already fills the chip
@@ -733,7 +752,7 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     }
     if (ctx->force_tile) { decode(ctx->force_tile); pinned = true; }
     if (ctx->autotune && !pinned && dma_ok && !ctx->gemm_probe) {      // 1: tune shapes not met before, 2: remembered shapes only
-        const fie_tune_key key{MODE, a.M, a.N, a.K, a.K1, MODE == 1 ? a.stride * 2 + a.ups + 8 * a.taps2 + 16 * (a.A2 != nullptr) + 32 * (a.A3 != nullptr) : 0, a.w_scale != nullptr};
+        const fie_tune_key key{MODE, a.M, a.N, a.K, a.K1, MODE == 1 ? a.stride * 2 + a.ups + 8 * a.taps2 + 16 * (a.A2 != nullptr) + 32 * (a.A3 != nullptr) : 0, a.w_scale == nullptr ? 0 : a.a_scale != 0.f ? 2 : 1};
         auto it = ctx->tuned.find(key);
         if (it != ctx->tuned.end()) {
             decode(it->second);
@@ -978,6 +997,33 @@ int fie_gemm_w8_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const vo
     FIE_REQUIRE(w_scale != nullptr, "fie_gemm_w8_f16: w_scale is NULL");
     return gemm_impl("fie_gemm_w8_f16", ctx, A1, lda1, K1, A2, lda2, W8packed, ldw, w_scale, C, ldc, M, N, K, bias, rowbias, ld_rowbias,
                      rows_per_batch, residual, ldr, scale, act);
+}
+
+// e4m3 activations x e4m3 weights (gemm_x8.hip).  A8: [M, K] e4m3 bytes written by a producer with out_f8 (fie_layernorm_f16_o8,
+// fie_attention_f16_o8, this entry with out_f8, fie_quantize_f8), row stride lda BYTES; W8packed / w_scale as fie_gemm_w8_f16 with ldw % 128 == 0.
+// C = epi(a_scale * w_scale[n] * (A8 . W8^T)): f16 [M, N] (ldc in elements) or, out_f8 != 0, e4m3 bytes of value * out_inv_scale (ldc in bytes).
+int fie_gemm_x8_f16(fie_ctx* ctx, const void* A8, int64_t lda, const void* W8packed, int64_t ldw, const float* w_scale, float a_scale, void* C, int64_t ldc,
+                    int M, int N, int K, const void* bias, const void* rowbias, int64_t ld_rowbias, int rows_per_batch, const void* residual, int64_t ldr,
+                    float scale, int act, int out_f8, float out_inv_scale) {
+    const char* who = "fie_gemm_x8_f16";
+    (void)grab_gn_target(ctx);
+    FIE_REQUIRE(ctx && A8 && W8packed && w_scale && C, "%s: NULL ctx/A/W/scale/C", who);
+    FIE_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0 && lda % 16 == 0 && lda >= K, "%s: bad shape M=%d N=%d K=%d lda=%lld (K, lda %% 16 == 0)", who, M, N, K, (long long)lda);
+    FIE_REQUIRE(ldw % 128 == 0 && ldw >= K, "%s: ldw=%lld must be a multiple of 128 covering K", who, (long long)ldw);
+    FIE_REQUIRE(a_scale > 0.f && (!out_f8 || out_inv_scale > 0.f), "%s: scales must be positive", who);
+    FIE_REQUIRE(!rowbias || rows_per_batch > 0, "%s: rowbias needs rows_per_batch", who);
+    if (int e = check_epilogue(who, N, out_f8 ? 4 : ldc, residual, ldr, act)) return e;
+    FIE_REQUIRE(!out_f8 || (ldc % 4 == 0 && !residual), "%s: fp8 output: ldc %% 4 == 0, no residual", who);
+    GemmArgs a = {};
+    a.A1 = (const half_t*)A8; a.lda1 = lda; a.K1 = K;
+    a.Wt = (const half_t*)W8packed; a.ldw = ldw; a.w_scale = w_scale; a.a_scale = a_scale; a.C = (half_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
+    a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    a.res = (const half_t*)residual; a.ldr = ldr; a.scale = scale; a.act = act;
+    a.out_f8 = out_f8; a.out_inv_scale = out_inv_scale;
+    a.a1_bytes = (int64_t)(M - 1) * lda + K;
+    a.w_bytes = fie_roundup(N, 128) * ldw;
+    return launch<0>(ctx, a);
 }
 
 static int conv_impl(const char* who, fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, int upsample2x, int stride, int pad_mode,

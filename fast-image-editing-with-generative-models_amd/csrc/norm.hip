@@ -157,6 +157,33 @@ __global__ __launch_bounds__(256) void gn_finalize_wide_kernel(GnArgsT<T> p, int
     }
 }
 
+// Large maps (512^2 / 1024^2 VAE tensors: 8 192 - 32 768 granules per image): the walk above reads one float2 per 256-byte row of the
+// producer's [granule][group] table from only B * G blocks (43 us at 1024^2).  First gather the granules with coalesced reads: block (i, b)
+// sums `per` consecutive granules for ALL groups (thread = (row lane, group): a wave instruction reads two whole table rows), fp64 in
+// registers, and writes one (sum, sum of squares) row in the layout of the ordinary chunk partials; gn_finalize_kernel then reduces the few
+// hundred rows.  Fixed assignment and order: deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_gather_granules_kernel(GnArgsT<T> p, const float* granules, int ngran, int per) {
+    __shared__ double red[256][2];
+    const int tid = threadIdx.x, g = tid % p.G, sub = tid / p.G, nsub = 256 / p.G;
+    const int b = blockIdx.y, c0 = blockIdx.x * per, c1 = min(c0 + per, ngran);
+    const float2* src = reinterpret_cast<const float2*>(granules) + (int64_t)b * ngran * p.G + g;
+    double a0 = 0.0, q0 = 0.0, a1 = 0.0, q1 = 0.0;
+    int c = c0 + sub;
+    for (; c + nsub < c1; c += 2 * nsub) {
+        const float2 v0 = src[(int64_t)c * p.G], v1 = src[(int64_t)(c + nsub) * p.G];
+        a0 += (double)v0.x; q0 += (double)v0.y; a1 += (double)v1.x; q1 += (double)v1.y;
+    }
+    if (c < c1) { const float2 v = src[(int64_t)c * p.G]; a0 += (double)v.x; q0 += (double)v.y; }
+    red[tid][0] = a0 + a1; red[tid][1] = q0 + q1;
+    __syncthreads();
+    if (sub == 0) {
+        double a = 0.0, q = 0.0;
+        for (int s = 0; s < nsub; ++s) { a += red[s * p.G + g][0]; q += red[s * p.G + g][1]; }
+        *reinterpret_cast<float2*>(p.partial + (((int64_t)b * gridDim.x + blockIdx.x) * p.G + g) * 2) = make_float2((float)a, (float)q);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgsT<T> p) {
     const int tid = threadIdx.x;
@@ -332,9 +359,10 @@ bool gn_onepass(fie_ctx* ctx, const GnArgsT<T>& p, int B) {
 // ---- LayerNorm: one wave per row, row kept in registers (C <= 4096)
 constexpr int LN_MAXV = 8;   // 8 chunks x 8 values per lane
 
-template <typename T>
+// O8: the output is written as e4m3 bytes, value * inv8 saturated to +-448 (fie_layernorm_f16_o8: the consumer is an fp8-activation GEMM)
+template <typename T, bool O8 = false>
 __global__ __launch_bounds__(256) void ln_kernel(const T* X, int64_t ldx, T* Y, int64_t ldy, int64_t rows,
-                                                 int C, const T* gamma, const T* beta, float eps) {
+                                                 int C, const T* gamma, const T* beta, float eps, float inv8 = 1.f) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -377,7 +405,17 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* X, int64_t ldx, T* Y, 
             fie_load8(beta + ch * 8, bb);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
-            fie_store8(Y + row * ldy + ch * 8, o);
+            if constexpr (O8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = fminf(fmaxf(o[j] * inv8, -448.f), 448.f);
+                int lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], lo, true);
+                int hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], 0, false);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[6], o[7], hi, true);
+                *reinterpret_cast<int2*>(reinterpret_cast<unsigned char*>(Y) + row * ldy + ch * 8) = make_int2(lo, hi);
+            } else {
+                fie_store8(Y + row * ldy + ch * 8, o);
+            }
         }
     }
 }
@@ -440,7 +478,7 @@ int layernorm_t(const char* who, fie_ctx* ctx, const void* X, int64_t ldx, void*
     FIE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "%s: C=%d unsupported", who, C);
     FIE_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "%s: bad strides", who);
     FIE_DESC(ctx, "layernorm rows=%lld C=%d bytes=%.0f", (long long)rows, C, 2.0 * rows * C * sizeof(T));
-    fie_launch(ctx, ln_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (const T*)X, ldx, (T*)Y, ldy, rows, C, (const T*)gamma, (const T*)beta, eps);
+    fie_launch(ctx, (ln_kernel<T, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (const T*)X, ldx, (T*)Y, ldy, rows, C, (const T*)gamma, (const T*)beta, eps, 1.f);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -467,8 +505,20 @@ int groupnorm_stats_t(const char* who, fie_ctx* ctx, const void* X, int C, void*
     GnArgsT<T> f = p;                                       // finalize walks the producer's granules, apply its own row chunks
     f.partial = const_cast<float*>((const float*)partial);
     f.nchunks = (int)(rows_per_image / 32);
-    FIE_DESC(ctx, "groupnorm finalize-from-epilogue B=%d rows=%lld C=%d G=%d bytes=0", B, (long long)rows_per_image, C, groups);
-    fie_launch(ctx, gn_finalize_wide_kernel<T>, dim3(B * groups), dim3(256), 0, f, B);
+    const int ngran = (int)(rows_per_image / 32);
+    if (ngran >= 4096 && groups <= 256 && 256 % groups == 0) {        // big maps: coalesced gather into <= 256 rows, then the ordinary finalize
+        const int nb = 256, per = (ngran + nb - 1) / nb;
+        GnArgsT<T> g2 = p;
+        g2.partial = (float*)workspace;                     // the chunk-partial area of the workspace is free on this path: [B][nb][G][2]
+        g2.nchunks = nb;
+        FIE_DESC(ctx, "groupnorm gather-granules B=%d rows=%lld C=%d G=%d bytes=%.0f", B, (long long)rows_per_image, C, groups, 8.0 * B * ngran * groups);
+        fie_launch(ctx, gn_gather_granules_kernel<T>, dim3(nb, B), dim3(256), 0, g2, (const float*)partial, ngran, per);
+        FIE_DESC(ctx, "groupnorm finalize B=%d rows=%lld C=%d G=%d bytes=0", B, (long long)rows_per_image, C, groups);
+        fie_launch(ctx, gn_finalize_kernel<T>, dim3((B * groups + 3) / 4), dim3(256), 0, g2, B);
+    } else {
+        FIE_DESC(ctx, "groupnorm finalize-from-epilogue B=%d rows=%lld C=%d G=%d bytes=0", B, (long long)rows_per_image, C, groups);
+        fie_launch(ctx, gn_finalize_wide_kernel<T>, dim3(B * groups), dim3(256), 0, f, B);
+    }
     FIE_DESC(ctx, "groupnorm apply B=%d rows=%lld C=%d G=%d bytes=%.0f", B, (long long)rows_per_image, C, groups, 2.0 * B * rows_per_image * C * sizeof(T));
     fie_launch(ctx, gn_apply_kernel<T>, grid, dim3(GN_THREADS), 0, p);
     FIE_LAUNCH_CHECK();
@@ -509,6 +559,21 @@ int fie_layernorm_f16(fie_ctx* ctx, const void* X, int64_t ldx, void* Y, int64_t
 int fie_layernorm_f32(fie_ctx* ctx, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t rows, int C,
                       const void* gamma, const void* beta, float eps) {
     return layernorm_t<float>("fie_layernorm_f32", ctx, X, ldx, Y, ldy, rows, C, gamma, beta, eps);
+}
+
+// LayerNorm with an e4m3 output (BASELINE config 5: the q/k/v, cross-attention query and FF1 projections read fp8 activations): Y8 [rows, C]
+// bytes, row stride ldy8 BYTES, value * inv_scale saturated to the e4m3 range.
+int fie_layernorm_f16_o8(fie_ctx* ctx, const void* X, int64_t ldx, void* Y8, int64_t ldy8, int64_t rows, int C, const void* gamma, const void* beta,
+                         float eps, float inv_scale) {
+    const char* who = "fie_layernorm_f16_o8";
+    FIE_REQUIRE(ctx && X && Y8 && gamma && beta, "%s: NULL argument", who);
+    FIE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV && inv_scale > 0.f, "%s: C=%d unsupported", who, C);
+    FIE_REQUIRE(ldx % 8 == 0 && ldy8 % 8 == 0 && ldx >= C && ldy8 >= C, "%s: bad strides", who);
+    FIE_DESC(ctx, "layernorm->e4m3 rows=%lld C=%d bytes=%.0f", (long long)rows, C, 3.0 * rows * C);
+    fie_launch(ctx, (ln_kernel<half_t, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (const half_t*)X, ldx, (half_t*)Y8, ldy8, rows, C,
+               (const half_t*)gamma, (const half_t*)beta, eps, inv_scale);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
 }
 
 }  // extern "C"

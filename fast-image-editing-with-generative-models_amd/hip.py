@@ -42,6 +42,10 @@ SIGNATURES = {
     "fie_pack_conv3x3_f8": [_P, _P, _I, _I, _I, _P, _L, _I, _P],
     "fie_gemm_w8_f16": [_P, _P, _L, _I, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P, _P, _L, _I, _P, _L, _F, _I],
     "fie_conv3x3_w8_nhwc_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P, _L, _I, _P, _P, _L, _P, _L, _F, _I],
+    "fie_gemm_x8_f16": [_P, _P, _L, _P, _L, _P, _F, _P, _L, _I, _I, _I, _P, _P, _L, _I, _P, _L, _F, _I, _I, _F],
+    "fie_layernorm_f16_o8": [_P, _P, _L, _P, _L, _L, _I, _P, _P, _F, _F],
+    "fie_attention_f16_o8": [_P, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I, _F],
+    "fie_quantize_f8": [_P, _P, _L, _P, _L, _L, _I, _F],
     "fie_attention_f16": [_P, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I],
     "fie_groupnorm_workspace_bytes": [_I, _L, _I],
     "fie_groupnorm_nhwc_f16": [_P, _P, _I, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P],
@@ -218,6 +222,9 @@ class Context:
         self.ws_tag = 0
         self._keep = None              # list collecting the tensors allocated while a program is being recorded (Context.record)
         self.w8 = False                # while True, pack_linear / pack_conv3x3 quantise eligible weights to fp8 e4m3 (see W8)
+        # fp8 ACTIVATIONS for the transformer-block projections of an fp8-weight model (csrc/gemm_x8.hip): the producers (LayerNorm, attention,
+        # the GEGLU epilogue) write e4m3 and the GEMMs run the block-scaled MFMA.  FIE_A8=0 keeps fp16 activations (round-2 behaviour: A/B)
+        self.a8 = os.environ.get("FIE_A8", "1") != "0"
 
     def fetch_device_errors(self):
         """Queues the 16-byte D2H copy of the error word on the current stream (call before a synchronisation that happens anyway)."""
@@ -359,6 +366,8 @@ class Context:
         w = w.to(self.device, torch.float16).contiguous()
         n, k = w.shape
         npad, kpad = (n + 127) // 128 * 128, (k + 63) // 64 * 64
+        if self.w8 and quant and self.a8:
+            kpad = (k + 127) // 128 * 128               # the fp8-activation kernels step K by 128
         if self.w8 and quant:
             q = torch.empty((npad, kpad), device=self.device, dtype=torch.uint8)
             scale = torch.empty((npad,), device=self.device, dtype=torch.float32)
@@ -412,8 +421,9 @@ class Context:
         return (buf, groups, n, rows_per_image, b, self._gn_gen, key)
 
     def gemm(self, a, wp, n, out=None, a2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None, scale=1.0,
-             act=ACT_NONE, k=None, gn_stats=None):
-        """a: [M, K1] (last-dim contiguous, row stride free), optional a2: [M, K2]; wp packed weight; n logical N."""
+             act=ACT_NONE, k=None, gn_stats=None, a_scale=1.0, out_f8=False, out_inv_scale=1.0):
+        """a: [M, K1] (last-dim contiguous, row stride free), optional a2: [M, K2]; wp packed weight; n logical N.
+        a of dtype uint8 = e4m3 activations (fie_gemm_x8_f16; a_scale = their dequantisation scale); out_f8: the output is e4m3 bytes too."""
         self.sync_stream()
         self._bind_splitk()
         m, k1 = a.shape
@@ -422,13 +432,21 @@ class Context:
             assert k == ktot
         nout = n // 2 if act == ACT_GEGLU else n
         if out is None:
-            out = self._alloc((m, nout))
+            out = self._alloc((m, nout), torch.uint8 if out_f8 else None)
         assert a.stride(1) == 1 and out.stride(1) == 1
         if self.f32:
             _chk(lib().fie_gemm_f32(self.h, _p(a), a.stride(0), k1, _p(a2), a2.stride(0) if a2 is not None else 0, _p(wp),
                                     wp.stride(0), 0, _p(out), out.stride(0), m, n, ktot, _p(bias), _p(rowbias),
                                     rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
                                     residual.stride(0) if residual is not None else 0, float(scale), act, 1, 1, 0, 0, 0, 0, 0, 0))
+            return out
+        if a.dtype == torch.uint8:                      # e4m3 activations (written by a producer with out_f8) x e4m3 weights
+            assert isinstance(wp, W8) and a2 is None and wp.stride(0) % 128 == 0, "fp8 activations need fp8 weights packed with Kpad % 128 == 0"
+            if out_f8 and out.dtype != torch.uint8:
+                raise ValueError("out_f8 needs a uint8 output tensor")
+            _chk(lib().fie_gemm_x8_f16(self.h, _p(a), a.stride(0), _p(wp.q), wp.stride(0), _p(wp.scale), float(a_scale), _p(out), out.stride(0), m, n, ktot,
+                                       _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
+                                       residual.stride(0) if residual is not None else 0, float(scale), act, int(out_f8), float(out_inv_scale)))
             return out
         if isinstance(wp, W8):
             _chk(lib().fie_gemm_w8_f16(self.h, _p(a), a.stride(0), k1, _p(a2), a2.stride(0) if a2 is not None else 0,
@@ -511,11 +529,11 @@ class Context:
         out._gn_tag = tag
         return out
 
-    def attention(self, q, k, v, heads, head_dim, tq, tk, batch, out=None, causal=False, scale=None):
-        """q: [B*Tq, >=H*D] view (row stride free); k, v: [B*Tk, ...]; returns [B*Tq, H*D]."""
+    def attention(self, q, k, v, heads, head_dim, tq, tk, batch, out=None, causal=False, scale=None, out_f8=False, out_inv_scale=1.0):
+        """q: [B*Tq, >=H*D] view (row stride free); k, v: [B*Tk, ...]; returns [B*Tq, H*D] (out_f8: as e4m3 bytes, value * out_inv_scale)."""
         self.sync_stream()
         if out is None:
-            out = self._alloc((batch * tq, heads * head_dim))
+            out = self._alloc((batch * tq, heads * head_dim), torch.uint8 if out_f8 else None)
         scale = scale if scale is not None else head_dim ** -0.5
         if self.f32:
             # S = Q K^T (batched over image x head) -> row softmax -> O = P V; the fp32 scores are simply materialised
@@ -528,6 +546,10 @@ class Context:
             _chk(lib().fie_gemm_f32(self.h, _p(s_), tk, tk, None, 0, _p(v), v.stride(0), 1, _p(out), out.stride(0), tq, d, tk, None,
                                     None, 0, 0, None, 0, 1.0, ACT_NONE, batch, heads, heads * tq * tk, tq * tk, tk * v.stride(0), d,
                                     tq * out.stride(0), d))
+            return out
+        if out_f8:
+            _chk(lib().fie_attention_f16_o8(self.h, _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), batch, heads, tq, tk,
+                                            head_dim, float(scale), int(causal), float(out_inv_scale)))
             return out
         _chk(lib().fie_attention_f16(self.h, _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
                                      out.stride(0), batch, heads, tq, tk, head_dim, float(scale), int(causal)))
@@ -558,9 +580,21 @@ class Context:
                                           _p(beta), float(eps), int(silu), _p(ws)))
         return out
 
-    def layernorm(self, x, gamma, beta, eps=1e-5, out=None):
+    def quantize_f8(self, x, inv_scale=1.0):
+        """[rows, C] f16 -> e4m3 bytes (value * inv_scale, saturated): the plain conversion (tests; producers without a fused form)."""
         self.sync_stream()
         rows, c = x.shape
+        out = self._alloc((rows, c), torch.uint8)
+        _chk(lib().fie_quantize_f8(self.h, _p(x), x.stride(0), _p(out), out.stride(0), rows, c, float(inv_scale)))
+        return out
+
+    def layernorm(self, x, gamma, beta, eps=1e-5, out=None, out_f8=False, out_inv_scale=1.0):
+        self.sync_stream()
+        rows, c = x.shape
+        if out_f8:
+            out = self._alloc((rows, c), torch.uint8) if out is None else out
+            _chk(lib().fie_layernorm_f16_o8(self.h, _p(x), x.stride(0), _p(out), out.stride(0), rows, c, _p(gamma), _p(beta), float(eps), float(out_inv_scale)))
+            return out
         if out is None:
             out = self._alloc((rows, c))
         _chk((lib().fie_layernorm_f32 if self.f32 else lib().fie_layernorm_f16)(self.h, _p(x), x.stride(0), _p(out), out.stride(0), rows, c, _p(gamma), _p(beta),

@@ -200,6 +200,26 @@ int fie_conv3x3_w8_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, in
                             const void* bias, const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ldr,
                             float scale, int act);
 
+/* ---- fp8 (OCP e4m3) ACTIVATIONS as well (config 5, round 3): the transformer-block projections of the UNet / ControlNet (upstream
+ * attention.py BasicTransformerBlock: to_q/k/v, to_out, GEGLU proj, FF out) read e4m3 activations written by their PRODUCER -- LayerNorm
+ * (fie_layernorm_f16_o8), attention (fie_attention_f16_o8), the FF1 GEGLU epilogue (fie_gemm_x8_f16 with out_f8) -- and multiply them with
+ * e4m3 weights on the block-scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: twice the fp16 MFMA rate and half the
+ * operand bytes.  Quantisation: value * inv_scale, round to nearest even, saturated to +-448; the consumer multiplies the fp32 accumulator by
+ * a_scale (= 1 / inv_scale of its input, one per tensor) * w_scale[n].  The residual stream, q/k/v and every GEMM output that is not a
+ * GEMM input stay fp16.
+ *   fie_gemm_x8_f16: A8 [M, K] e4m3 bytes (row stride lda BYTES, K % 16 == 0, lda % 16 == 0); W8packed / w_scale from fie_pack_rows_f8 with
+ *     ldw % 128 == 0; epilogue as fie_gemm_f16; out_f8 != 0: C is e4m3 bytes (value * out_inv_scale; ldc in BYTES; GEGLU: N / 2 bytes per row;
+ *     no residual), else f16 (ldc in elements).
+ *   fie_quantize_f8: plain f16 -> e4m3 conversion of a [rows, C] tensor (tests; producers without a fused form). */
+int fie_gemm_x8_f16(fie_ctx* ctx, const void* A8, int64_t lda, const void* W8packed, int64_t ldw, const float* w_scale, float a_scale, void* C, int64_t ldc,
+                    int M, int N, int K, const void* bias, const void* rowbias, int64_t ld_rowbias, int rows_per_batch, const void* residual, int64_t ldr,
+                    float scale, int act, int out_f8, float out_inv_scale);
+int fie_layernorm_f16_o8(fie_ctx* ctx, const void* X, int64_t ldx, void* Y8, int64_t ldy8, int64_t rows, int C, const void* gamma, const void* beta,
+                         float eps, float inv_scale);
+int fie_attention_f16_o8(fie_ctx* ctx, const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O8, int64_t ldo8,
+                         int B, int H, int Tq, int Tk, int D, float scale, int causal, float inv_scale);
+int fie_quantize_f8(fie_ctx* ctx, const void* X, int64_t ldx, void* Y8, int64_t ldy, int64_t rows, int C, float inv_scale);
+
 /* ---- fp32 path (`FastEditor(use_full_precision=True)`, run_batch.py --full_precision / --quality_mode; reference:
  * src/pipeline.py:67-71,94-99).  Same graphs, fp32 storage, exact fp32 arithmetic on v_mfma_f32_16x16x4_f32.
  *   fie_gemm_f32: as fie_gemm_f16 with plain (unpacked) weights W [N][ldw] -- or [K][ldw] when w_is_kn -- and a two-level

@@ -143,6 +143,107 @@ def test_fp8_pipeline_against_fp16_pipeline(fie):
         HipImg2ImgPipeline(fie, cfgs, sds, weight_dtype="int4")
 
 
+@pytest.mark.parametrize("code", [0, 42, 43, 47, 51, 52, 54, 62, 63, 30062, 20051, 20054])
+def test_gemm_x8_fp8_activations_matches_quantised_reference(fie8, code):
+    """fie_gemm_x8_f16 (csrc/gemm_x8.hip): e4m3 activations x e4m3 weights on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales.
+    The reference multiplies the SAME quantised operands in fp32, so only the summation order and the store's rounding differ: every tile
+    code, K tails (K % 128 != 0), ragged M / N, bias + row bias + SiLU + scale + in-place residual, an activation scale, GEGLU with an e4m3
+    OUTPUT, a plain e4m3 output, split-K; an identity product with an asymmetric integer weight checks the operand maps of the instruction."""
+    from fie_amd import hip
+    fie8.force_tile(code)
+    for m, n, k in [(2048, 1280, 1280), (300, 200, 128), (1000, 640, 272), (77, 960, 2048), (2048, 1280, 5120)]:
+        a, w, bias, res, rb = rnd(m, k, seed=1, scale=2.0), rnd(n, k, seed=2, scale=k ** -0.5), rnd(n, seed=3), rnd(m, n, seed=4), rnd(2, n, seed=5)
+        wp = fie8.pack_linear(w.to(DEV))
+        assert wp.stride(0) % 128 == 0
+        a8 = fie8.quantize_f8(a.to(DEV), 0.5)                         # stored value = a / 2  ->  a_scale = 2
+        aq = a8.view(torch.float8_e4m3fn).float().cpu()
+        assert torch.equal(aq, q8(a.float() * 0.5))
+        inplace = res.to(DEV).clone()
+        out = fie8.gemm(a8, wp, n, bias=bias.to(DEV), rowbias=rb.to(DEV), rows_per_batch=(m + 1) // 2, residual=inplace, out=inplace, scale=0.5,
+                        act=hip.ACT_SILU, a_scale=2.0)
+        assert "fp8 activations" in hip.last_gemm_kernel(fie8), hip.last_gemm_kernel(fie8)
+        wq = wp.q.view(torch.float8_e4m3fn).float().cpu()[:n, :k]
+        lin = (aq @ wq.T) * 2.0 * wp.scale[:n].cpu() + bias.float() + rb.float().repeat_interleave((m + 1) // 2, 0)[:m]
+        assert rel_err(out, F.silu(lin) * 0.5 + res.float()) < 2e-3, (m, n, k)
+        # e4m3 output (what a following fp8-activation GEMM reads): value / 4, saturated
+        o8 = fie8.gemm(a8, wp, n, bias=bias.to(DEV), a_scale=2.0, out_f8=True, out_inv_scale=0.25)
+        assert o8.dtype == torch.uint8 and o8.shape == (m, n)
+        want = q8(((aq @ wq.T) * 2.0 * wp.scale[:n].cpu() + bias.float()) * 0.25)
+        got = o8.view(torch.float8_e4m3fn).float().cpu()
+        assert (got == want).float().mean() > 0.995 and rel_err(got, want) < 0.13, (m, n, k)      # a value on a rounding boundary may land one code off
+    # GEGLU (FF1) with an e4m3 output
+    a, wg, bg = rnd(1000, 1280, seed=11), rnd(520, 1280, seed=12, scale=1280 ** -0.5), rnd(520, seed=13)
+    wp = fie8.pack_linear(wg.to(DEV), geglu=True)
+    a8 = fie8.quantize_f8(a.to(DEV))
+    o8 = fie8.gemm(a8, wp, 520, act=hip.ACT_GEGLU, out_f8=True, bias=torch.stack([bg[:260], bg[260:]], 1).reshape(-1).contiguous().to(DEV))
+    assert o8.shape == (1000, 260)
+    wq = fie8.pack_linear(wg.to(DEV)).dequant().cpu()[:520, :1280]       # same bytes, rows not interleaved
+    full = q8(a) @ wq.T + bg.float()
+    want = q8(full[:, :260] * F.gelu(full[:, 260:]))
+    got = o8.view(torch.float8_e4m3fn).float().cpu()
+    assert (got == want).float().mean() > 0.99 and rel_err(got, want) < 0.13
+    # operand maps: identity activations x an asymmetric small-integer weight (exact in e4m3)
+    eye8 = fie8.quantize_f8(torch.eye(256, dtype=torch.float16).to(DEV))
+    w = ((torch.arange(256 * 256, dtype=torch.float32).reshape(256, 256) % 13) - 6).half()
+    wp = fie8.pack_linear(w.to(DEV))
+    out = fie8.gemm(eye8, wp, 256)
+    assert rel_err(out, wp.dequant().cpu()[:256, :256].T) < 1e-3
+
+
+def test_fp8_producers_layernorm_and_attention(fie):
+    """The producers of fp8 activations: LayerNorm and attention with an e4m3 output equal the fp16 op followed by the saturating
+    round-to-nearest-even conversion (their fp32 values are converted once, so a code may differ where the fp16 rounding of the plain op moved
+    a value across an e4m3 boundary); values beyond +-448 saturate instead of turning into NaN."""
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(2048, 1280, generator=g) * 3).half()
+    gam, bet = (1 + 0.2 * torch.randn(1280, generator=g)).half(), (0.1 * torch.randn(1280, generator=g)).half()
+    y16 = fie.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV))
+    y8 = fie.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), out_f8=True, out_inv_scale=2.0)
+    got, want = y8.view(torch.float8_e4m3fn).float().cpu(), q8(y16.float().cpu() * 2.0)
+    assert (got == want).float().mean() > 0.98 and rel_err(got, want) < 0.13
+    big = fie.layernorm(x.to(DEV), (gam * 400).to(DEV), bet.to(DEV), out_f8=True).view(torch.float8_e4m3fn).float()
+    assert torch.isfinite(big).all() and big.abs().max() == 448
+    q, k, v = (torch.randn(2 * 1024, 640, generator=g).half().to(DEV) for _ in range(3))
+    o16 = fie.attention(q, k, v, 10, 64, 1024, 1024, 2)
+    o8 = fie.attention(q, k, v, 10, 64, 1024, 1024, 2, out_f8=True, out_inv_scale=8.0)
+    got, want = o8.view(torch.float8_e4m3fn).float().cpu(), q8(o16.float().cpu() * 8.0)
+    assert (got == want).float().mean() > 0.98 and rel_err(got, want) < 0.13
+    kx = torch.randn(2 * 77, 640, generator=g).half().to(DEV)
+    o8 = fie.attention(q, kx, kx, 10, 64, 1024, 77, 2, out_f8=True)
+    want = q8(fie.attention(q, kx, kx, 10, 64, 1024, 77, 2).float().cpu())
+    assert (o8.view(torch.float8_e4m3fn).float().cpu() == want).float().mean() > 0.98
+
+
+def test_fp8_activation_block_matches_the_fp16_activation_block(fie):
+    """One BasicTransformerBlock at the real width (2 x 1024 tokens x 1280) with fp8 weights: the fp8-ACTIVATION flow (producers write e4m3,
+    block-scaled MFMA) against the round-2 flow (fp16 activations converted per fragment inside the GEMM).  Both multiply the same e4m3
+    values except where the round-2 flow rounds twice (fp32 -> fp16 -> e4m3 moves a value across an e4m3 boundary for ~1-2 % of the elements,
+    one code = 6 % of that element): a few percent of a block output's max-abs, measured 1.2e-2."""
+    import math
+    from fie_amd import weights
+    from fie_amd.nn import TBlock
+    p = "transformer_blocks.0."
+    table = [r for r in weights._transformer2d("", 1280, 1, 2048) if r[0].startswith(p)]
+    gen = torch.Generator().manual_seed(11)
+    sd = {}
+    for name, shape, kind in table:
+        w = 1.0 + 0.2 * torch.randn(shape, generator=gen) if kind == "g" else 0.1 * torch.randn(shape, generator=gen) if kind == "b" else \
+            torch.randn(shape, generator=gen) / math.sqrt(math.prod(shape[1:])) * (0.5 if kind == "wo" else 1.0)
+        sd[name] = w.half()
+    x = torch.randn(2 * 1024, 1280, generator=gen).half().to(DEV)
+    text = torch.randn(2 * 77, 2048, generator=gen).half().to(DEV)
+    outs = {}
+    for a8 in (True, False):
+        fie.w8, fie.a8 = True, a8
+        try:
+            blk = TBlock(fie, sd, p, 1280, 64)
+        finally:
+            fie.w8, fie.a8 = False, True
+        assert blk.a8 == a8
+        outs[a8] = blk(fie, x, text, 2, 1024, 77).float().cpu()
+    assert rel_err(outs[True], outs[False]) < 3e-2
+
+
 def test_fp8_full_size_ssim_vs_fp16(fie):
     """BASELINE size (SSD-1B-A' + ControlNet-full, 1024x1024, 2 evals, CFG): fp8-weight pipeline against the fp16 pipeline on the
     same synthetic weights and noise -- the parity gate VERDICT r1 set for config 5: SSIM >= 0.99 (512x512 metric resolution, as
