@@ -167,6 +167,8 @@ __device__ __forceinline__ void read_frags(f16x8 (&f)[N], unsigned addr, std::in
     ((f[I] = lds_read16_async<I * 16 * BK * 2>(addr)), ...);
 }
 
+// (Round 3 negative result: issuing the K-step's DMA pieces one at a time BETWEEN the MFMAs of the 4-wave tiles, instead of as one burst in
+// front of them, is 15-30 % slower on every hot-path GEMM -- profiles/r03_interleaved_dma_issue_negative.log -- and was removed again.)
 template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0
 __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     constexpr int WGN = NW / 2;

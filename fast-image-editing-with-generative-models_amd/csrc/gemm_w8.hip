@@ -5,7 +5,7 @@
 //   * weights: e4m3 with ONE fp32 scale per output channel (scale[n] = max_k |W[n,k]| / 448), packed [Npad][Kpad] bytes, K contiguous;
 //     the scale is applied to the fp32 accumulator in the epilogue, in front of bias / activation / residual;
 //   * activations stay fp16 in HBM and in LDS; the wave converts each 16 x 32 activation fragment to e4m3 in registers
-//     (v_cvt_scalef32_pk_fp8_f16, scale 1: saturating round-to-nearest-even) right before
+//     (clamp to +-448, then v_cvt_scalef32_pk_fp8_f16 at scale 1: round-to-nearest-even; the instruction itself does not saturate) right before
 //     v_mfma_f32_16x16x32_fp8_fp8 (fp32 accumulate).  Non-scaled fp8 MFMA runs at the fp16 rate on gfx950
 //     (MI355X_MICROARCH.md, Matrix cores): what fp8 weights buy is half the weight bytes in HBM and half the weight pieces through the
 //     per-CU global->LDS path that paces these kernels.
@@ -21,12 +21,19 @@ namespace {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
+// v_cvt_scalef32_pk_fp8_f16 does NOT saturate: a magnitude beyond 448 converts to the e4m3 NaN (measured, tests/test_fp8_gpu.py
+// ::test_fp8_activations_beyond_e4m3_range_saturate; round 2 shipped it unclamped).  Two packed f16 min / max per pair clamp first.
+__device__ __forceinline__ f16x2 clamp448(f16x2 x) {
+    const f16x2 hi = {(half_t)448.f, (half_t)448.f}, lo = {(half_t)-448.f, (half_t)-448.f};
+    return __builtin_elementwise_max(__builtin_elementwise_min(x, hi), lo);
+}
+
 __device__ __forceinline__ long f16x8_to_fp8x8(const f16x8& v) {
     s16x2 lo = {0, 0}, hi = {0, 0};
-    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, (f16x2){v[0], v[1]}, 1.0f, false);
-    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, (f16x2){v[2], v[3]}, 1.0f, true);
-    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, (f16x2){v[4], v[5]}, 1.0f, false);
-    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, (f16x2){v[6], v[7]}, 1.0f, true);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, clamp448((f16x2){v[0], v[1]}), 1.0f, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(lo, clamp448((f16x2){v[2], v[3]}), 1.0f, true);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, clamp448((f16x2){v[4], v[5]}), 1.0f, false);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(hi, clamp448((f16x2){v[6], v[7]}), 1.0f, true);
     return (long)(unsigned)__builtin_bit_cast(int, lo) | ((long)__builtin_bit_cast(int, hi) << 32);
 }
 

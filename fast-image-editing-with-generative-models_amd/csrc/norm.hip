@@ -28,6 +28,8 @@ struct GnArgsT {
     float eps; int silu;
     float* partial;          // [B][nchunks][G][2]
     float* stats;            // [B][G][2] mean, rstd
+    int pg;                  // producer-written partials only (gn_finalize_wide_kernel): slots per granule row; 0 = G.  pg > G: group g is the sum
+                             // of the pg / G consecutive slots (4-channel quads) from g * pg / G on -- the 20 / 40-channel groups of the UNet
 };
 
 using GnArgs = GnArgsT<half_t>;
@@ -125,8 +127,19 @@ __global__ __launch_bounds__(256) void gn_finalize_wide_kernel(GnArgsT<T> p, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x;
     const int b = i / p.G, g = i - b * p.G;
-    const float2* src = reinterpret_cast<const float2*>(p.partial) + (int64_t)b * p.nchunks * p.G + g;
     double a0 = 0.0, q0 = 0.0, a1 = 0.0, q1 = 0.0, a2 = 0.0, q2 = 0.0, a3 = 0.0, q3 = 0.0;
+    if (p.pg > p.G) {
+        // quad partials: thread = (granule, quad of this group); fixed assignment and order -> deterministic
+        const int upg = p.pg / p.G;
+        const float2* src = reinterpret_cast<const float2*>(p.partial) + (int64_t)b * p.nchunks * p.pg + g * upg;
+        const int total = p.nchunks * upg;
+        for (int i = tid; i < total; i += 256) {
+            const int c = i / upg, u = i - c * upg;
+            const float2 v = src[(int64_t)c * p.pg + u];
+            a0 += (double)v.x; q0 += (double)v.y;
+        }
+    } else {
+    const float2* src = reinterpret_cast<const float2*>(p.partial) + (int64_t)b * p.nchunks * p.G + g;
     int c = tid;
     for (; c + 768 < p.nchunks; c += 1024) {
         const float2 v0 = src[(int64_t)c * p.G], v1 = src[(int64_t)(c + 256) * p.G], v2 = src[(int64_t)(c + 512) * p.G], v3 = src[(int64_t)(c + 768) * p.G];
@@ -136,6 +149,7 @@ __global__ __launch_bounds__(256) void gn_finalize_wide_kernel(GnArgsT<T> p, int
     for (; c < p.nchunks; c += 256) {
         const float2 v = src[(int64_t)c * p.G];
         a0 += (double)v.x; q0 += (double)v.y;
+    }
     }
     double a = (a0 + a1) + (a2 + a3), q = (q0 + q1) + (q2 + q3);
 #pragma unroll
@@ -490,7 +504,7 @@ int layernorm_t(const char* who, fie_ctx* ctx, const void* X, int64_t ldx, void*
 // instead of two.
 template <typename T>
 int groupnorm_stats_t(const char* who, fie_ctx* ctx, const void* X, int C, void* Y, int B, int64_t rows_per_image, int groups, const void* gamma,
-                      const void* beta, float eps, int silu, const void* partial, void* workspace) {
+                      const void* beta, float eps, int silu, const void* partial, void* workspace, int partial_groups) {
     FIE_REQUIRE(ctx && X && Y && gamma && beta && partial && workspace, "%s: NULL argument", who);
     FIE_REQUIRE(C > 0 && C % 8 == 0 && B > 0 && groups > 0 && C % groups == 0 && rows_per_image > 0 && rows_per_image % 32 == 0,
                 "%s: bad shape C=%d G=%d rows=%lld", who, C, groups, (long long)rows_per_image);
@@ -505,8 +519,11 @@ int groupnorm_stats_t(const char* who, fie_ctx* ctx, const void* X, int C, void*
     GnArgsT<T> f = p;                                       // finalize walks the producer's granules, apply its own row chunks
     f.partial = const_cast<float*>((const float*)partial);
     f.nchunks = (int)(rows_per_image / 32);
+    FIE_REQUIRE(partial_groups == 0 || partial_groups == groups || (partial_groups > groups && partial_groups % groups == 0 && partial_groups * 4 == C),
+                "%s: partial_groups=%d must be 0, the group count, or C / 4 quads divisible into the %d groups", who, partial_groups, groups);
+    f.pg = partial_groups;
     const int ngran = (int)(rows_per_image / 32);
-    if (ngran >= 4096 && groups <= 256 && 256 % groups == 0) {        // big maps: coalesced gather into <= 256 rows, then the ordinary finalize
+    if (ngran >= 4096 && groups <= 256 && 256 % groups == 0 && partial_groups <= groups) {        // big maps: coalesced gather into <= 256 rows, then the ordinary finalize
         const int nb = 256, per = (ngran + nb - 1) / nb;
         GnArgsT<T> g2 = p;
         g2.partial = (float*)workspace;                     // the chunk-partial area of the workspace is free on this path: [B][nb][G][2]
@@ -530,8 +547,9 @@ extern "C" {
 int64_t fie_gn_stats_bytes(int B, int64_t rows_per_image, int groups) { return (int64_t)B * (rows_per_image / 32) * groups * 2 * (int64_t)sizeof(float); }
 
 int fie_groupnorm_stats_nhwc_f16(fie_ctx* ctx, const void* X, int C, void* Y, int B, int64_t rows_per_image, int groups, const void* gamma,
-                                 const void* beta, float eps, int silu, const void* partial, void* workspace) {
-    return groupnorm_stats_t<half_t>("fie_groupnorm_stats_nhwc_f16", ctx, X, C, Y, B, rows_per_image, groups, gamma, beta, eps, silu, partial, workspace);
+                                 const void* beta, float eps, int silu, const void* partial, void* workspace, int partial_groups) {
+    return groupnorm_stats_t<half_t>("fie_groupnorm_stats_nhwc_f16", ctx, X, C, Y, B, rows_per_image, groups, gamma, beta, eps, silu, partial, workspace,
+                                     partial_groups);
 }
 
 int64_t fie_groupnorm_workspace_bytes(int B, int64_t rows_per_image, int groups) {

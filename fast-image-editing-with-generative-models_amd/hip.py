@@ -85,7 +85,7 @@ SIGNATURES = {
     "fie_conv_up2x_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P, _L, _I, _P, _L, _I, _P, _P, _L, _F, _I],
     "fie_gn_stats_target": [_P, _P, _L, _I],
     "fie_gn_stats_bytes": [_I, _L, _I],
-    "fie_groupnorm_stats_nhwc_f16": [_P, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _P],
+    "fie_groupnorm_stats_nhwc_f16": [_P, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _P, _I],
     "fie_gemm_autotune": [_P, _I],
     "fie_gemm_autotune_report": [_P, ctypes.c_char_p, _I],
     "fie_debug_tune_exclude": [_P, ctypes.c_char_p],
@@ -216,6 +216,7 @@ class Context:
         self._sk_bound = None
         self.splitk_bytes = int(os.environ.get("FIE_SPLITK_MB", "96")) << 20      # 0: never split K
         self.gn_from_epilogue = os.environ.get("FIE_GN_FROM_EPILOGUE", "1") != "0"
+        self.gn_quads = os.environ.get("FIE_GN_QUADS", "1") != "0"      # ... also for the UNet's 20 / 40-channel groups (quad partials); A/B switch
         self.up2x_parity = os.environ.get("FIE_UP2X_PARITY", "1") != "0"
         self.conv_plus_shortcut = os.environ.get("FIE_CONV_PLUS", "1") != "0"   # resnet conv2 + 1x1 shortcut as one GEMM (fie_conv3x3_plus_nhwc_f16)      # 2x-upsampling convs as four 2x2 convs (fie_conv_up2x_nhwc_f16)
         self._resize_tables = {}       # (in, out) -> (taps, bounds, ksize) of the LANCZOS resample, on the device
@@ -377,7 +378,7 @@ class Context:
         _chk(lib().fie_pack_rows_f16(self.h, _p(w), k, n, k, _p(out), kpad, npad, int(geglu)))
         return out
 
-    def pack_conv3x3(self, w, cin_pad=None):
+    def pack_conv3x3(self, w, cin_pad=None, quant=True):
         """OIHW f16 -> packed [Npad][Kpad], k = (ky*3+kx)*cin_pad + ci.  fp32 contexts: [Cout][9*cin_pad] fp32."""
         self.sync_stream()
         if self.f32:
@@ -390,7 +391,7 @@ class Context:
         co, ci = w.shape[:2]
         cin_pad = cin_pad or (ci + 7) // 8 * 8
         npad, kpad = (co + 127) // 128 * 128, (9 * cin_pad + 63) // 64 * 64
-        if self.w8 and cin_pad % 64 == 0:          # the fp8 kernels are the LDS-DMA ones: K-steps must not straddle a 3x3 tap
+        if self.w8 and quant and cin_pad % 64 == 0:  # the fp8 kernels are the LDS-DMA ones: K-steps must not straddle a 3x3 tap
             q = torch.empty((npad, kpad), device=self.device, dtype=torch.uint8)
             scale = torch.empty((npad,), device=self.device, dtype=torch.float32)
             _chk(lib().fie_pack_conv3x3_f8(self.h, _p(w), co, ci, cin_pad, _p(q), kpad, npad, _p(scale)))
@@ -404,21 +405,28 @@ class Context:
     def _gn_stats_arm(self, rows_total, n, rows_per_image, groups):
         """Arms the next launch to write GroupNorm partial sums of its [rows_total, n] output; returns the tag groupnorm() looks for on
         the output tensor, or None when the shape is not eligible (channels per group not 4 / 8 / 16, rows not in 32-row granules)."""
-        if not self.gn_from_epilogue or self.f32 or not groups or n % groups or n // groups not in (4, 8, 16):
+        if not self.gn_from_epilogue or self.f32 or not groups or n % groups:
             return None
         if rows_per_image % 32 or rows_total % rows_per_image:
             return None
+        cg, pgroups = n // groups, groups
+        if cg not in (4, 8, 16):
+            # the UNet's 20 / 40-channel groups: the producer writes one slot per 4-channel quad and the consumer sums the quads of a group.
+            # Only where the three-kernel GroupNorm would run (64x64 latents and up): the small maps take the single-pass kernel, one launch
+            if cg % 4 or rows_per_image < 4096 or not self.gn_quads:
+                return None
+            pgroups = n // 4
         b = rows_total // rows_per_image
-        need = lib().fie_gn_stats_bytes(b, rows_per_image, groups)
+        need = lib().fie_gn_stats_bytes(b, rows_per_image, pgroups)
         key = (self._stream, self.ws_tag)            # one buffer per stream and graph slot: a producer's sums are consumed before the next producer runs
         buf = self._gn_stats.get(key)
         if buf is None or buf.numel() < need:
             buf = self._gn_stats[key] = torch.empty(need, device=self.device, dtype=torch.uint8)
         if self._keep is not None:
             self._keep.append(buf)
-        _chk(lib().fie_gn_stats_target(self.h, _p(buf), rows_per_image, groups))
+        _chk(lib().fie_gn_stats_target(self.h, _p(buf), rows_per_image, pgroups))
         self._gn_gen += 1
-        return (buf, groups, n, rows_per_image, b, self._gn_gen, key)
+        return (buf, groups, n, rows_per_image, b, self._gn_gen, key, pgroups)
 
     def gemm(self, a, wp, n, out=None, a2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None, scale=1.0,
              act=ACT_NONE, k=None, gn_stats=None, a_scale=1.0, out_f8=False, out_inv_scale=1.0):
@@ -574,7 +582,7 @@ class Context:
         if (tag is not None and x2 is None and tag[1:5] == (groups, c1, rows, b) and tag[5] == self._gn_gen and tag[6] == key):
             # the producer's epilogue left this tensor's partial sums (and nothing has overwritten them): one read of x instead of two
             _chk(lib().fie_groupnorm_stats_nhwc_f16(self.h, _p(x1), c1, _p(out), b, rows, groups, _p(gamma), _p(beta), float(eps), int(silu),
-                                                    _p(tag[0]), _p(ws)))
+                                                    _p(tag[0]), _p(ws), tag[7]))
             return out
         _chk((lib().fie_groupnorm_nhwc_f32 if self.f32 else lib().fie_groupnorm_nhwc_f16)(self.h, _p(x1), c1, _p(x2), c2, _p(out), b, rows, groups, _p(gamma),
                                           _p(beta), float(eps), int(silu), _p(ws)))

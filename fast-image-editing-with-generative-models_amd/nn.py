@@ -54,7 +54,9 @@ class Conv3:
         self.cin_pad = cin_pad or (self.cin + 7) // 8 * 8
         self.ldc = cout_pad or self.cout
         self.n = (self.cout + 3) // 4 * 4          # kernel writes whole 4-channel groups (extra ones are zeros)
-        self.wp = ctx.pack_conv3x3(w, self.cin_pad)
+        # fp8-weight models (config 5): the 1280-wide convs of the 32x32-latent level stay fp16 -- M = 2048 rows fill the chip only with split-K, which
+        # the fp16 ring kernels have and the fp8-weight conv kernel has not (79 vs 109 us for 1280 -> 1280, profiles/r03_per_shape_roofline_fp8.md)
+        self.wp = ctx.pack_conv3x3(w, self.cin_pad, quant=self.cout < 1280)
         # up-sampler convs (diffusers: "...upsamplers.0.conv") run as four 2x2 parity convs (hip.py: pack_conv_up2x).  Packed HERE, not at
         # the first call: a first call inside a launch-program recording would record the pack launches instead of running them.
         self.wp4 = None
@@ -183,7 +185,10 @@ class Transformer2D:
         h = self.pin(ctx, h)
         for blk in self.blocks:
             h = blk(ctx, h, text, b, hh * ww, text_len)
-        return self.pout(ctx, h, residual=xt).view(b, hh, ww, c)
+        o = self.pout(ctx, h, residual=xt, gn_stats=(hh * ww, self.groups))     # the next resnet's norm1 reads this tensor: its sums ride on the epilogue
+        y = o.view(b, hh, ww, c)
+        y._gn_tag = getattr(o, "_gn_tag", None)            # the view is a new tensor object: carry the producer's GroupNorm sums along
+        return y
 
     def reset(self):
         for blk in self.blocks:
@@ -291,7 +296,7 @@ class _CondNet:
                     x = t(ctx, x, text, text_len)
                 skips.append(x)
             if ds is not None:
-                x = ds(ctx, x, stride=2)
+                x = ds(ctx, x, stride=2, gn_groups=self.cfg["norm_num_groups"])
                 skips.append(x)
         for r, t in self.mid:
             if t:

@@ -291,11 +291,15 @@ int fie_conv_up2x_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int
  * granule and per group, the sum and the sum of squares of the f16-ROUNDED outputs: partial[B][rows_per_image / 32][groups][2] floats
  * (fie_gn_stats_bytes).  N / groups must be 4, 8 or 16 channels (the SDXL VAE's 128 / 256 / 512-channel maps with 32 groups); no GEGLU.
  * Every slot has one writer: deterministic.  fie_groupnorm_stats_nhwc_f16 is fie_groupnorm_nhwc_f16 for such a tensor: it reduces the
- * partials (fp64) and applies, reading X once instead of twice; workspace as for fie_groupnorm_nhwc_f16. */
+ * partials (fp64) and applies, reading X once instead of twice; workspace as for fie_groupnorm_nhwc_f16.
+ * Group widths that are not 4 / 8 / 16 but a multiple of 4 (the UNet's 20 / 40 channels per group at 640 / 1280 channels): arm the producer
+ * with groups = N / 4 (it then writes one slot per 4-channel QUAD, which is all a lane of the MFMA layout can sum without crossing a group
+ * border) and pass partial_groups = N / 4 to fie_groupnorm_stats_nhwc_f16, which sums the N / 4 / groups quads of each real group
+ * (partial_groups 0 or == groups: slots are groups, as above). */
 int fie_gn_stats_target(fie_ctx* ctx, void* partial, int64_t rows_per_image, int groups);
 int64_t fie_gn_stats_bytes(int B, int64_t rows_per_image, int groups);
 int fie_groupnorm_stats_nhwc_f16(fie_ctx* ctx, const void* X, int C, void* Y, int B, int64_t rows_per_image, int groups, const void* gamma,
-                                 const void* beta, float eps, int silu, const void* partial, void* workspace);
+                                 const void* beta, float eps, int silu, const void* partial, void* workspace, int partial_groups);
 
 /* Touches one dword of every 128-byte line of [ptr, ptr + bytes) with `blocks` small workgroups on `stream` (NULL: the context's): pulls a
  * weight matrix from HBM into the Infinity Cache ahead of the kernel that will stream it.  Reads only; no result. */

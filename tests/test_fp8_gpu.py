@@ -190,6 +190,19 @@ def test_gemm_x8_fp8_activations_matches_quantised_reference(fie8, code):
     assert rel_err(out, wp.dequant().cpu()[:256, :256].T) < 1e-3
 
 
+def test_fp8_activations_beyond_e4m3_range_saturate(fie8):
+    """ADVICE r2 (gemm_w8.hip:24): activations beyond +-448 SATURATE in both fp8 flows (per-fragment conversion inside the fp8-weight GEMM,
+    fie_quantize_f8 for the fp8-activation GEMM) -- finite, equal to the clamped reference -- instead of turning into NaN."""
+    a, w = rnd(256, 256, seed=1, scale=300.0), rnd(128, 256, seed=2, scale=256 ** -0.5)
+    assert a.float().abs().max() > 448
+    wp = fie8.pack_linear(w.to(DEV))
+    wq = wp.q.view(torch.float8_e4m3fn).float().cpu()[:128, :256]
+    ref = q8(a) @ wq.T * wp.scale[:128].cpu()
+    o_w8 = fie8.gemm(a.to(DEV), wp, 128)
+    o_x8 = fie8.gemm(fie8.quantize_f8(a.to(DEV)), wp, 128)
+    assert torch.isfinite(o_w8.float()).all() and rel_err(o_w8, ref) < 2e-3 and rel_err(o_x8, ref) < 2e-3
+
+
 def test_fp8_producers_layernorm_and_attention(fie):
     """The producers of fp8 activations: LayerNorm and attention with an e4m3 output equal the fp16 op followed by the saturating
     round-to-nearest-even conversion (their fp32 values are converted once, so a code may differ where the fp16 rounding of the plain op moved

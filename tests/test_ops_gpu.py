@@ -288,13 +288,14 @@ def test_gemm_conv_every_shipped_kernel(fie, code):
             fie.force_tile(0)
 
 
-def test_ring_256x320_tile_gemm_view(fie):
-    """Tile code 63 (256x320, 8 waves, wave tile 128x80, two-stage ring): the exact-fit tile of the FF1 projection (M 2048 x N 10240:
-    256 tiles = one per CU).  GEGLU at the real shape, ragged M / N / K with bias + row bias + SiLU + scale + in-place residual, the
-    [A1 | A2] column concatenation, against fp32 torch; the conv view refuses the code loudly."""
+@pytest.mark.parametrize("code", [63])
+def test_gemm_view_only_tiles(fie, code):
+    """Tile code built for the GEMM view only: 63 (256x320, 8 waves, wave tile 128x80, two-stage ring: the exact-fit tile of the FF1
+    projection, M 2048 x N 10240 = 256 tiles = one per CU).  GEGLU at the real shape, ragged M / N / K with bias + row bias + SiLU + scale + in-place
+    residual, the [A1 | A2] column concatenation, against fp32 torch; the conv view refuses the code loudly."""
     from fie_amd import hip
     try:
-        fie.force_tile(63)
+        fie.force_tile(code)
         a, w, b = rnd(2048, 1280, seed=1), rnd(10240, 1280, seed=2, scale=1280 ** -0.5), rnd(10240, seed=3)
         out = fie.gemm(a.to(DEV), fie.pack_linear(w.to(DEV), geglu=True), 10240, act=hip.ACT_GEGLU,
                        bias=torch.stack([b[:5120], b[5120:]], 1).reshape(-1).contiguous().to(DEV))
@@ -627,6 +628,39 @@ def test_groupnorm_statistics_from_the_producing_conv(fie, cout, code):
     o4._gn_tag = o._gn_tag
     assert o._gn_tag is not None
     assert rel_err(fie.groupnorm(o4, gamma, beta, groups, 1e-6, False), fie.groupnorm(o4.clone(), gamma, beta, groups, 1e-6, False).float()) < 1e-3
+
+
+@pytest.mark.parametrize("cout,code", [(640, 0), (1280, 96), (640, 42), (1280, 30096), (640, 52)])
+def test_groupnorm_statistics_for_20_and_40_channel_groups(fie, cout, code):
+    """The UNet's group widths (640 / 1280 channels in 32 groups = 20 / 40 channels: not a whole number of a lane's 4 output columns per
+    16-column fragment): the producer writes one slot per 4-channel QUAD (armed with N / 4 'groups'), the consumer sums the 5 / 10 quads of
+    each real group.  Conv, conv + 1x1 side inputs and GEMM (+ residual) producers at 64x64 'latents' (4096 rows per image: below that the
+    single-pass GroupNorm runs and nothing is armed), against the three-kernel GroupNorm of the same tensor and torch."""
+    b, h, w, cin, groups = 2, 64, 64, 128, 32
+    x = rnd(b, h, w, cin, seed=1).to(DEV)
+    wc = fie.pack_conv3x3(rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5).to(DEV))
+    bias = rnd(cout, seed=3).to(DEV)
+    gamma, beta = (1 + 0.1 * rnd(cout, seed=5)).to(DEV), (0.1 * rnd(cout, seed=6)).to(DEV)
+    fie.force_tile(code)
+    try:
+        y = fie.conv3x3(x, wc, cout, bias=bias, gn_groups=groups)
+        a2d, wl = rnd(b * h * w, 128, seed=7).to(DEV), fie.pack_linear(rnd(cout, 128, seed=8, scale=128 ** -0.5).to(DEV))
+        o = fie.gemm(a2d, wl, cout, bias=bias, residual=y.view(b * h * w, cout), gn_stats=(h * w, groups))
+    finally:
+        fie.force_tile(0)
+    assert o._gn_tag is not None and o._gn_tag[7] == cout // 4
+    o4 = o.view(b, h, w, cout)
+    o4._gn_tag = o._gn_tag
+    fast = fie.groupnorm(o4, gamma, beta, groups, 1e-5, True)
+    slow = fie.groupnorm(o4.clone(), gamma, beta, groups, 1e-5, True)
+    ref = F.silu(F.group_norm(o4.float().permute(0, 3, 1, 2), groups, gamma.float(), beta.float(), 1e-5)).permute(0, 2, 3, 1)
+    assert rel_err(fast, slow.float()) < 1e-3 and rel_err(fast, ref) < 4e-3
+    # the conv's own sums were overwritten by the GEMM producer: its GroupNorm takes the plain path and still agrees
+    assert torch.equal(fie.groupnorm(y, gamma, beta, groups, 1e-5, True), fie.groupnorm(y.clone(), gamma, beta, groups, 1e-5, True))
+    y2 = fie.conv3x3(x, wc, cout, bias=bias, gn_groups=groups)
+    assert y2._gn_tag is not None and rel_err(fie.groupnorm(y2, gamma, beta, groups, 1e-5, False), fie.groupnorm(y2.clone(), gamma, beta, groups, 1e-5, False).float()) < 1e-3
+    small = fie.conv3x3(x[:, :32, :32].contiguous(), wc, cout, gn_groups=groups)       # 1024 rows per image: single-pass GroupNorm, nothing armed
+    assert small._gn_tag is None
 
 
 def test_gn_stats_target_is_disarmed_by_a_failing_call(fie):

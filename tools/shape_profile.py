@@ -30,7 +30,8 @@ def run(out_path, model="ssd-1b"):
     import torch
     from bench import synth_item_image
     from src.pipeline import FastEditor
-    ed = FastEditor(model_name=model, use_full_controlnet=True, enable_cpu_offload=False)
+    kw = {"weight_dtype": os.environ["FIE_PROFILE_WEIGHTS"]} if os.environ.get("FIE_PROFILE_WEIGHTS") else {}      # "f8e4m3": BASELINE config 5
+    ed = FastEditor(model_name=model, use_full_controlnet=True, enable_cpu_offload=False, **kw)
     pipe, ctx = ed.pipe, ed.pipe.ctx
     pipe.fork_streams = False
     pipe.use_graph = False
