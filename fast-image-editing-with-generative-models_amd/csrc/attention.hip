@@ -250,15 +250,17 @@ __device__ __forceinline__ void attn_bload16(__amdgpu_buffer_rsrc_t rsrc, half_t
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
-template <int D, int QF, int KT>
-__global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
+// NWV = waves per block (4; 2 = the "narrow" form: 64 queries per block as 2 waves x 32 queries, see fie_attention_f16): a wave re-reads the whole K / V
+// tile from LDS for its 16 * QF queries, so QF = 1 needs 1 KiB of fragment reads per MFMA -- the full LDS bandwidth of a CU at the MFMA rate.
+template <int D, int QF, int KT, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void attn2_kernel(AttnArgs p) {
     constexpr int KF = KT / 16, DK = D / 32, DF = D / 16, PS = KT / 32;
     constexpr int CH = D / 8;                  // 16-byte chunks per row
     constexpr int RP = 64 / CH > 0 ? 64 / CH : 1;   // rows per 1-KiB LDS-DMA piece (8 for D=64, 1 for D=512)
     constexpr int PPR = CH / 64 > 0 ? CH / 64 : 1;  // pieces per row (1)
     static_assert(PPR == 1, "row longer than one LDS-DMA piece");
     constexpr int NPT = KT / RP;               // pieces per K (or V) tile
-    constexpr int PW = 2 * NPT / 4;            // pieces per wave per tile (K and V)
+    constexpr int PW = 2 * NPT / NWV;          // pieces per wave per tile (K and V)
     constexpr int TILE = KT * D;               // halfs
     constexpr float THR = 6.0f;
     extern __shared__ __attribute__((aligned(16))) half_t smem[];
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * (64 * QF) + wave * (16 * QF);
+    const int q0 = blockIdx.x * (NWV * 16 * QF) + wave * (16 * QF);
 
     const half_t* Qb = p.Q + (int64_t)b * p.Tq * p.ldq + h * D;
     const half_t* Kb = p.K + (int64_t)b * p.Tk * p.ldk + h * D;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
     unsigned pvoff[PW];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
-        const int pc = wave + 4 * i;
+        const int pc = wave + NWV * i;
         const bool isv = pc >= NPT;
         const int row = (isv ? pc - NPT : pc) * RP + prow;
         pvoff[i] = (unsigned)row * (unsigned)(isv ? p.ldv : p.ldk) * 2u + (unsigned)(pphys ^ (row & 7)) * 16u;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
         const unsigned sok = (unsigned)(t * KT) * (unsigned)p.ldk * 2u, sov = (unsigned)(t * KT) * (unsigned)p.ldv * 2u;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            const int pc = wave + 4 * i;
+            const int pc = wave + NWV * i;
             const bool isv = pc >= NPT;
             const int pr = isv ? pc - NPT : pc;
             // (the builtin must sit in a __device__ helper: used directly in the __global__ body, the host pass silently
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
     };
 
     int kend = p.Tk;
-    if (p.causal) kend = min(kend, min(p.Tq, (int)(blockIdx.x + 1) * 64 * QF));
+    if (p.causal) kend = min(kend, min(p.Tq, (int)(blockIdx.x + 1) * NWV * 16 * QF));
     const int ntiles = (kend + KT - 1) / KT;
     issue(0, 0);
 
@@ -465,11 +467,12 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnArgs p) {
     }
 }
 
-template <int D, int QF, int KT>
+template <int D, int QF, int KT, int NWV = 4>
 int launch_attn2(fie_ctx* ctx, const AttnArgs& a, int B) {
     const size_t lds = (size_t)4 * KT * D * sizeof(half_t);
-    const dim3 grid((unsigned)((a.Tq + 64 * QF - 1) / (64 * QF)), (unsigned)a.H, (unsigned)B), block(256);
-    fie_launch(ctx, (attn2_kernel<D, QF, KT>), grid, block, lds, a);
+    constexpr int QB = NWV * 16 * QF;                     // queries per block
+    const dim3 grid((unsigned)((a.Tq + QB - 1) / QB), (unsigned)a.H, (unsigned)B), block(NWV * 64);
+    fie_launch(ctx, (attn2_kernel<D, QF, KT, NWV>), grid, block, lds, a);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -487,6 +490,7 @@ int fie_attn_init(void) {
     hipError_t e = attn_attrs<512, 1, 32>();
     if (e == hipSuccess) e = attn_attrs<64, 2, 64>();
     if (e == hipSuccess) e = attn_attrs<64, 1, 64>();
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<64, 2, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * (int)sizeof(half_t));
     if (e != hipSuccess) {
         fie_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return FIE_EHIP;
@@ -517,8 +521,12 @@ static int attention_impl(fie_ctx* ctx, const void* Q, int64_t ldq, const void* 
     }
     if (D == 512) return launch_attn2<512, 1, 32>(ctx, a, B);
     if (ctx->attn_variant == 2) return launch_attn2<64, 2, 64>(ctx, a, B);      // A/B: 128 queries per block everywhere
-    if (ctx->attn_variant == 3) return launch_attn2<64, 1, 64>(ctx, a, B);      // A/B: 64 queries per block everywhere
-    if (blocks128 >= ctx->num_cus * 2) return launch_attn2<64, 2, 64>(ctx, a, B);
+    if (ctx->attn_variant == 3) return launch_attn2<64, 1, 64>(ctx, a, B);      // A/B: 64 queries per block as 4 waves x 16 everywhere
+    if (ctx->attn_variant == 4) return launch_attn2<64, 2, 64, 2>(ctx, a, B);   // A/B: 64 queries per block as TWO waves x 32 (half the LDS fragment reads per MFMA)
+    // Round 3, whole UNet forward (profiles/r03_attention_block_forms_in_unet.log): 16 queries per wave everywhere 15.24 ms; 32 per wave for the
+    // 4096-token maps (the round-2 rule) 15.40-15.44 ms, whether the small maps run 4 x 16 or 2 x 32 -- so 128-query blocks only for grids of
+    // four and more waves of them (batched jobs), where the round-2 measurements were taken
+    if (blocks128 >= ctx->num_cus * 4) return launch_attn2<64, 2, 64>(ctx, a, B);
     return launch_attn2<64, 1, 64>(ctx, a, B);
 }
 
@@ -537,7 +545,7 @@ extern "C" int fie_attention_f16_o8(fie_ctx* ctx, const void* Q, int64_t ldq, co
 }
 
 extern "C" int fie_debug_attn_variant(fie_ctx* ctx, int v) {
-    FIE_REQUIRE(ctx != nullptr && v >= 0 && v <= 3, "fie_debug_attn_variant: bad argument");
+    FIE_REQUIRE(ctx != nullptr && v >= 0 && v <= 4, "fie_debug_attn_variant: bad argument");
     ctx->attn_variant = v;
     return FIE_OK;
 }

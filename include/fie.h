@@ -321,7 +321,7 @@ const char* fie_debug_last_gemm_kernel(fie_ctx* ctx);              /* kernel / t
 int fie_debug_oplog(fie_ctx* ctx, int on);                         /* launch log for the per-shape profile (tools/shape_profile.py): while on, every launch appends "kernel symbol|blocks|threads|LDS bytes|op description (shape, tile code, algorithmic flop / bytes)" */
 int fie_debug_oplog_mark(fie_ctx* ctx, const char* text);           /* appends "#text" (a stage boundary) when the log is on */
 int64_t fie_debug_oplog_read(fie_ctx* ctx, char* buf, int64_t cap);  /* newline-joined log into buf when it fits; returns its length (cap 0: size query) */
-int fie_debug_attn_variant(fie_ctx* ctx, int variant);   /* per context; 0 = default kernel, 1 = first-generation kernel, 2 / 3 = 128 / 64 queries per block forced (A/B benchmarking) */
+int fie_debug_attn_variant(fie_ctx* ctx, int variant);   /* per context; 0 = default kernel, 1 = first-generation kernel, 2 / 3 = 128 / 64 queries per block forced, 4 = 64 queries per block as two waves x 32 (A/B benchmarking) */
 int fie_debug_gn_onepass(fie_ctx* ctx, int enable);      /* per context; 1 = default (single-pass GroupNorm on small maps), 0 = always partial/finalize/apply */
 
 /* ---- K11 Canny on the host (integer exact).  Replaces cv2.cvtColor(RGB2GRAY) + cv2.Canny at
