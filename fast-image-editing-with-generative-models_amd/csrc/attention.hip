@@ -252,7 +252,8 @@ __device__ __forceinline__ void attn_bload16(__amdgpu_buffer_rsrc_t rsrc, half_t
 
 // NWV = waves per block (4; 2 = the "narrow" form: 64 queries per block as 2 waves x 32 queries, see fie_attention_f16): a wave re-reads the whole K / V
 // tile from LDS for its 16 * QF queries, so QF = 1 needs 1 KiB of fragment reads per MFMA -- the full LDS bandwidth of a CU at the MFMA rate.
-template <int D, int QF, int KT, int NWV = 4>
+// ST = stages of the K / V ring: 2 = tile t+1 in flight during tile t behind a full vmcnt(0); 3 = two tiles ahead behind a counted wait.
+template <int D, int QF, int KT, int NWV = 4, int ST = 2>
 __global__ __launch_bounds__(NWV * 64) void attn2_kernel(AttnArgs p) {
     constexpr int KF = KT / 16, DK = D / 32, DF = D / 16, PS = KT / 32;
     constexpr int CH = D / 8;                  // 16-byte chunks per row
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(NWV * 64) void attn2_kernel(AttnArgs p) {
     if (p.causal) kend = min(kend, min(p.Tq, (int)(blockIdx.x + 1) * NWV * 16 * QF));
     const int ntiles = (kend + KT - 1) / KT;
     issue(0, 0);
+    if (ST == 3 && ntiles > 1) issue(1, 1);
 
     // Q fragments, pre-scaled so that scores are already in the log2 domain
     f16x8 qf_[QF][DK];
@@ -352,9 +354,11 @@ __global__ __launch_bounds__(NWV * 64) void attn2_kernel(AttnArgs p) {
 
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT;
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // tile t landed; tile t-1 fully consumed
-        if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
-        const half_t* sk = smem + (t & 1) * 2 * TILE;
+        if (ST == 3 && t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(ST == 3 ? PW : 0) : "memory");   // tile t landed (t+1 may still fly)
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // tile t landed; tile t-1 fully consumed
+        if (ST == 3) { if (t + 2 < ntiles) issue(t + 2, (t + 2) % 3); }
+        else if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
+        const half_t* sk = smem + (ST == 3 ? t % 3 : t & 1) * 2 * TILE;
         const half_t* sv = sk + TILE;
 
         // the score chains start from the persistent -m_ref registers (C operand of the first MFMA): no per-tile init
@@ -467,12 +471,12 @@ __global__ __launch_bounds__(NWV * 64) void attn2_kernel(AttnArgs p) {
     }
 }
 
-template <int D, int QF, int KT, int NWV = 4>
+template <int D, int QF, int KT, int NWV = 4, int ST = 2>
 int launch_attn2(fie_ctx* ctx, const AttnArgs& a, int B) {
-    const size_t lds = (size_t)4 * KT * D * sizeof(half_t);
+    const size_t lds = (size_t)2 * ST * KT * D * sizeof(half_t);
     constexpr int QB = NWV * 16 * QF;                     // queries per block
     const dim3 grid((unsigned)((a.Tq + QB - 1) / QB), (unsigned)a.H, (unsigned)B), block(NWV * 64);
-    fie_launch(ctx, (attn2_kernel<D, QF, KT, NWV>), grid, block, lds, a);
+    fie_launch(ctx, (attn2_kernel<D, QF, KT, NWV, ST>), grid, block, lds, a);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -491,6 +495,7 @@ int fie_attn_init(void) {
     if (e == hipSuccess) e = attn_attrs<64, 2, 64>();
     if (e == hipSuccess) e = attn_attrs<64, 1, 64>();
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<64, 2, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * (int)sizeof(half_t));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<64, 1, 64, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 64 * (int)sizeof(half_t));
     if (e != hipSuccess) {
         fie_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return FIE_EHIP;
@@ -523,6 +528,7 @@ static int attention_impl(fie_ctx* ctx, const void* Q, int64_t ldq, const void* 
     if (ctx->attn_variant == 2) return launch_attn2<64, 2, 64>(ctx, a, B);      // A/B: 128 queries per block everywhere
     if (ctx->attn_variant == 3) return launch_attn2<64, 1, 64>(ctx, a, B);      // A/B: 64 queries per block as 4 waves x 16 everywhere
     if (ctx->attn_variant == 4) return launch_attn2<64, 2, 64, 2>(ctx, a, B);   // A/B: 64 queries per block as TWO waves x 32 (half the LDS fragment reads per MFMA)
+    if (ctx->attn_variant == 5) return launch_attn2<64, 1, 64, 4, 3>(ctx, a, B);   // A/B: three-stage K / V ring (two tiles ahead, counted vmcnt)
     // Round 3, whole UNet forward (profiles/r03_attention_block_forms_in_unet.log): 16 queries per wave everywhere 15.24 ms; 32 per wave for the
     // 4096-token maps (the round-2 rule) 15.40-15.44 ms, whether the small maps run 4 x 16 or 2 x 32 -- so 128-query blocks only for grids of
     // four and more waves of them (batched jobs), where the round-2 measurements were taken
@@ -545,7 +551,7 @@ extern "C" int fie_attention_f16_o8(fie_ctx* ctx, const void* Q, int64_t ldq, co
 }
 
 extern "C" int fie_debug_attn_variant(fie_ctx* ctx, int v) {
-    FIE_REQUIRE(ctx != nullptr && v >= 0 && v <= 4, "fie_debug_attn_variant: bad argument");
+    FIE_REQUIRE(ctx != nullptr && v >= 0 && v <= 5, "fie_debug_attn_variant: bad argument");
     ctx->attn_variant = v;
     return FIE_OK;
 }

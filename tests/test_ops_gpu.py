@@ -123,6 +123,26 @@ def test_attention(fie, b, hn, tq, tk, d, causal):
     assert rel_err(out, ref) < 4e-3
 
 
+@pytest.mark.parametrize("variant", [2, 3, 4, 5])
+def test_attention_ab_variants_agree(fie, variant):
+    """The A/B forms of the d = 64 kernel (fie_debug_attn_variant: 2 / 3 = 128 / 64 queries per block, 4 = two waves x 32 queries, 5 = three-stage
+    K / V ring with a counted vmcnt) compute what the default does: self-attention, the 77-key cross-attention, CLIP's causal 77 x 77, a ragged
+    length that ends inside a key tile."""
+    from fie_amd import hip
+    g = torch.Generator().manual_seed(variant)
+    cases = [(2, 10, 1024, 1024, False), (2, 20, 256, 77, False), (2, 12, 77, 77, True), (1, 4, 333, 200, False)]
+    try:
+        for b, hn, tq, tk, causal in cases:
+            q, k, v = (torch.randn(b * t, hn * 64, generator=g).half().to(DEV) for t in (tq, tk, tk))
+            assert hip.lib().fie_debug_attn_variant(fie.h, 0) == 0
+            ref = fie.attention(q, k, v, hn, 64, tq, tk, b, causal=causal).float()
+            assert hip.lib().fie_debug_attn_variant(fie.h, variant) == 0
+            out = fie.attention(q, k, v, hn, 64, tq, tk, b, causal=causal).float()
+            assert rel_err(out, ref) < 2e-3, (b, hn, tq, tk, causal)
+    finally:
+        hip.lib().fie_debug_attn_variant(fie.h, 0)
+
+
 def test_attention_fused_qkv_strides(fie):
     # q, k, v as column slices of one fused projection buffer (row stride 3C)
     b, hn, t, d = 1, 4, 256, 64
