@@ -379,5 +379,5 @@ int fie_gemm_init(void);           // same for the kernels of gemm_conv.hip
 int fie_launch_gemm_w8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int conv, int code);
 int fie_gemm_w8_init(void);
 // gemm_x8.hip: e4m3 activations x e4m3 weights on the block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales), GEMM view only
-int fie_launch_gemm_x8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int code);
+int fie_launch_gemm_x8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int code, int conv);
 int fie_gemm_x8_init(void);

@@ -565,7 +565,8 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     }
     const bool x8 = a.w_scale && a.a_scale != 0.f;           // e4m3 activations x e4m3 weights (gemm_x8.hip): its own tile set
     if (x8) {
-        FIE_REQUIRE(dma_ok && MODE == 0, "fp8 activations: GEMM view on the LDS-DMA kernels only");
+        FIE_REQUIRE(dma_ok && !a.A2 && !a.taps2, "fp8 activations: plain GEMM / 3x3 conv views on the LDS-DMA kernels only");
+        if (MODE == 1 && code == 63) code = 62;
         code = code == 96 || code == 81 || code == 61 ? 62 : code == 95 ? 51 : code == 44 || code == 2 ? 42 : code == 46 || code == 3 || code == 1 ? 43 : code;
         FIE_REQUIRE(code == 42 || code == 43 || code == 47 || code == 51 || code == 52 || code == 54 || code == 62 || code == 63, "tile code %d has no fp8-activation kernel", code);
         for (const TileDim& d : kTiles)
@@ -596,7 +597,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     if (x8) {
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "gemm3x8_kernel<%dx%d> (gemm, fp8 activations x fp8 weights, tile code %d%s", t->bm, t->bn, code, split > 1 ? "" : ")");
         if (split > 1) snprintf(ctx->last_kernel + strlen(ctx->last_kernel), 24, ", split-K %d)", split);
-        return fie_launch_gemm_x8(ctx, a, code);
+        return fie_launch_gemm_x8(ctx, a, code, MODE == 1);
     }
     if (a.w_scale) {
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "gemm3w8_kernel<%dx%d> (%s, fp8 weights, tile code %d)", t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
@@ -701,6 +702,7 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
         if ((c == 43 || c == 46) && blocks(64, 64) > 64 * ctx->num_cus) continue;       // tens of thousands of tiny tiles: never wins
         if ((c == 81 || c == 96 || c == 62) && 2 * blocks(256, 128) < ctx->num_cus) continue;
         if (c == 63 && (MODE != 0 || a.N % 320 != 0 || 2 * blocks(256, 320) < ctx->num_cus)) continue;
+        if (x8 && MODE == 1 && c == 63) continue;
         if (x8 && (c == 62 || c == 51) && 2 * blocks(c == 62 ? 256 : 128, 128) < ctx->num_cus) continue;
         if (c == 81 && MODE == 1 && a.A2) continue;            // side inputs: ring kernels only
         const float tc = time_of(c);
@@ -741,7 +743,7 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     // ... and an epilogue on 32-bit buffer offsets (gemm_common.h): output / residual spans of at most 1 GiB
     const int64_t c_span = ((int64_t)((a.oscat ? 4 * (int64_t)a.M : a.M) - 1) * a.ldc + a.N) * 2, r_span = a.res ? ((int64_t)(a.M - 1) * a.ldr + a.N) * 2 : 0;
     const bool dma_ok = a.a1_bytes < (1ll << 31) && a.a2_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) && c_span <= (1ll << 30) && r_span <= (1ll << 30) &&
-                        (MODE == 1 ? a.Cin % BK == 0 : (a.K1 == a.K || a.K1 % BK == 0));
+                        (MODE == 1 ? a.Cin % (a.a_scale != 0.f ? 2 * BK : BK) == 0 : (a.K1 == a.K || a.K1 % BK == 0));
     FIE_REQUIRE(!(MODE == 1 && a.A2 && !dma_ok), "conv + 1x1 side inputs: tensors too large for the LDS-DMA kernels");
     int code = heuristic_code<MODE>(ctx, a, dma_ok);
     int order = -1;                // 0: n-tiles fastest (an XCD owns a range of activation rows), 1: m-tiles fastest; -1: estimate
@@ -1065,6 +1067,37 @@ static int conv_impl(const char* who, fie_ctx* ctx, const void* X, int B, int H,
         FIE_REQUIRE(a.a2_bytes < (1ll << 31) && a.a3_bytes < (1ll << 31), "%s: side inputs too large", who);
     }
     a.w_bytes = fie_roundup(Cout, 128) * ldw * (w_scale ? 1 : 2);
+    if (int rc = take_gn_target(who, gn, a)) return rc;
+    return launch<1>(ctx, a);
+}
+
+// 3x3 conv on e4m3 activations (written by fie_groupnorm_nhwc_f16_o8 / fie_groupnorm_stats_nhwc_f16_o8) and e4m3 weights (fie_pack_conv3x3_f8 with
+// cin_pad == Cin, Cin % 128 == 0): the conv view of gemm_x8.hip, a K-step = 128 channels of one tap.  Y is f16 (ldc in elements).
+int fie_conv3x3_x8_nhwc_f16(fie_ctx* ctx, const void* X8, int B, int H, int W, int Cin, int upsample2x, int stride, int pad_mode, const void* W8packed,
+                            int64_t ldw, const float* w_scale, float a_scale, void* Y, int64_t ldc, int Cout, const void* bias, const void* rowbias,
+                            int64_t ld_rowbias, const void* residual, int64_t ldr, float scale, int act) {
+    const char* who = "fie_conv3x3_x8_nhwc_f16";
+    const GnTarget gn = grab_gn_target(ctx);
+    FIE_REQUIRE(ctx && X8 && W8packed && w_scale && Y, "%s: NULL ctx/X/W/scale/Y", who);
+    FIE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 128 == 0 && Cout > 0 && a_scale > 0.f, "%s: bad shape (Cin %% 128 == 0)", who);
+    FIE_REQUIRE((stride == 1 || stride == 2) && (pad_mode == 0 || pad_mode == 1) && act != FIE_ACT_GEGLU, "%s: stride / pad_mode / act", who);
+    const int K = 9 * Cin;
+    FIE_REQUIRE(ldw % 128 == 0 && ldw >= K, "%s: ldw=%lld must be a multiple of 128 covering 9*Cin", who, (long long)ldw);
+    if (int e = check_epilogue(who, Cout, ldc, residual, ldr, act)) return e;
+    const int ups = upsample2x ? 1 : 0;
+    const int Hin = H << ups, Win = W << ups;
+    const int pads = pad_mode == 0 ? 2 : 1;
+    const int OH = (Hin + pads - 3) / stride + 1, OW = (Win + pads - 3) / stride + 1;
+    FIE_REQUIRE((int64_t)B * OH * OW < (1ll << 31), "%s: too many output pixels", who);
+    GemmArgs a = {};
+    a.A1 = (const half_t*)X8; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.stride = stride;
+    a.pt = a.pl = pad_mode == 0 ? 1 : 0; a.ups = ups;
+    a.Wt = (const half_t*)W8packed; a.ldw = ldw; a.w_scale = w_scale; a.a_scale = a_scale; a.C = (half_t*)Y; a.ldc = ldc;
+    a.M = B * OH * OW; a.N = Cout; a.K = K; a.K1 = K;
+    a.bias = (const half_t*)bias; a.rowbias = (const half_t*)rowbias; a.ld_rowbias = ld_rowbias;
+    a.rows_per_batch = OH * OW; a.res = (const half_t*)residual; a.ldr = ldr; a.scale = scale; a.act = act;
+    a.a1_bytes = (int64_t)B * H * W * Cin;
+    a.w_bytes = fie_roundup(Cout, 128) * ldw;
     if (int rc = take_gn_target(who, gn, a)) return rc;
     return launch<1>(ctx, a);
 }

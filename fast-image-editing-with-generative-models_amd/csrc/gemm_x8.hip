@@ -21,7 +21,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int KE = 128;                   // k-values per K-step (one 128-byte row)
 constexpr int kUnitScale = 0x7F7F7F7F;    // E8M0 127 in every byte: block scale 2^0
 
-template <int BM, int BN, int ST, int NW>
+template <int BM, int BN, int ST, int NW, int MODE = 0>      // MODE 0 = GEMM view, 2 = 3x3 conv view (im2col of an NHWC e4m3 tensor, Cin % 128 == 0)
 __global__ __launch_bounds__(NW * 64) void gemm3x8_kernel(GemmArgs p) {
     constexpr int WGN = NW / 2;
     constexpr int WM = BM / 2, WN = BN / WGN;
@@ -57,11 +57,49 @@ __global__ __launch_bounds__(NW * 64) void gemm3x8_kernel(GemmArgs p) {
     const int nk = (int)((int64_t)nk_all * (slice + 1) / nsplit) - kbeg;
     const bool ktail = (p.K % KE) != 0;
 
+    // conv view: per-lane pixel coordinates of this lane's row in each of its RA pieces; a K-step = 128 channels of one tap
+    int a_ih[RA], a_iw[RA];
+    unsigned a_img[RA], a_off[RA];
+    bool a_ok[RA];
+    const int csteps = MODE == 2 ? p.Cin / KE : 1;
+    int ftap = kbeg / csteps, cs = kbeg - ftap * csteps;
+    bool tap_fresh = true;
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = m0 + (wave + NW * i) * 8 + lr;
+            a_ok[i] = m < p.M;
+            const int hw = p.OH * p.OW;
+            const int b = m / hw, rem = m - b * hw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            a_ih[i] = oh * p.stride - p.pt;
+            a_iw[i] = ow * p.stride - p.pl;
+            a_img[i] = (unsigned)b * (unsigned)(p.H * p.W) * (unsigned)p.Cin;
+            a_off[i] = kOob;
+        }
+    }
+
     auto issue = [&](int kt, int stage) {
         unsigned char* sa = smx + stage * STAGE;
         unsigned char* sw = sa + BM * 128;
         const unsigned so = (unsigned)kt * KE;
-        if (ktail && kt == nk_all - 1) {                            // last, partial K-step: k >= K reads as zero (K % 16 == 0)
+        if constexpr (MODE == 2) {
+            if (cs == 0 || tap_fresh) {
+                tap_fresh = false;
+                const int ky = (ftap * 11) >> 5, kx = ftap - 3 * ky;
+                const int hlim = p.H << p.ups, wlim = p.W << p.ups;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const int ih = a_ih[i] + ky, iw = a_iw[i] + kx;
+                    const bool ok = a_ok[i] && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+                    a_off[i] = ok ? a_img[i] + (unsigned)((ih >> p.ups) * p.W + (iw >> p.ups)) * (unsigned)p.Cin + c8 * 16u : kOob;
+                }
+            }
+            const unsigned soa = (unsigned)cs * KE;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) bload16(rs_a, reinterpret_cast<half_t*>(sa + (wave + NW * i) * 1024), a_off[i], soa);
+            if (++cs == csteps) { cs = 0; ++ftap; }
+        } else if (ktail && kt == nk_all - 1) {                            // last, partial K-step: k >= K reads as zero (K % 16 == 0)
             const bool in_k = kt * KE + c8 * 16 < p.K;
 #pragma unroll
             for (int i = 0; i < RA; ++i) bload16(rs_a, reinterpret_cast<half_t*>(sa + (wave + NW * i) * 1024), in_k ? a_base + (unsigned)i * a_step : kOob, so);
@@ -136,12 +174,16 @@ constexpr int x8_lds() { return ST * (BM + BN) * 128; }
 
 template <int BM, int BN, int ST, int NW>
 hipError_t x8_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3x8_kernel<BM, BN, ST, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, x8_lds<BM, BN, ST>());
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3x8_kernel<BM, BN, ST, NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, x8_lds<BM, BN, ST>());
+    if (e == hipSuccess && BN != 320)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3x8_kernel<BM, BN, ST, NW, BN == 320 ? 0 : 2>), hipFuncAttributeMaxDynamicSharedMemorySize, x8_lds<BM, BN, ST>());
+    return e;
 }
 
 template <int BM, int BN, int ST, int NW>
-void launch_x8(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
-    fie_launch(ctx, (gemm3x8_kernel<BM, BN, ST, NW>), grid, dim3(NW * 64), x8_lds<BM, BN, ST>(), a);
+void launch_x8(fie_ctx* ctx, const GemmArgs& a, dim3 grid, int conv) {
+    if (conv) fie_launch(ctx, (gemm3x8_kernel<BM, BN, ST, NW, BN == 320 ? 0 : 2>), grid, dim3(NW * 64), x8_lds<BM, BN, ST>(), a);
+    else fie_launch(ctx, (gemm3x8_kernel<BM, BN, ST, NW, 0>), grid, dim3(NW * 64), x8_lds<BM, BN, ST>(), a);
 }
 
 // ---- e4m3 conversion of an fp16 activation tensor (tests, and producers that have no fused form): y = sat(x * inv_scale)
@@ -183,17 +225,18 @@ int fie_gemm_x8_init(void) {
 
 // code: 42 / 43 / 47 (128x64 / 64x64 / 128x96, 4 waves, 3 stages), 51 / 62 (128x128 / 256x128, 8 waves, 3 stages), 52 / 54 (128x128 / 192x128, 2 stages),
 // 63 (256x320, 2 stages); the grid carries the split-K factor (a.splitk)
-int fie_launch_gemm_x8(fie_ctx* ctx, const GemmArgs& a, int code) {
+int fie_launch_gemm_x8(fie_ctx* ctx, const GemmArgs& a, int code, int conv) {
     const dim3 grid((unsigned)(a.nbm * a.nbn * (a.splitk > 1 ? a.splitk : 1)));
+    if (conv && code == 63) { fie_set_error("fie_launch_gemm_x8: tile code 63 is built for the GEMM view only"); return FIE_EINVAL; }
     switch (code) {
-        case 42: launch_x8<128, 64, 3, 4>(ctx, a, grid); break;
-        case 43: launch_x8<64, 64, 3, 4>(ctx, a, grid); break;
-        case 47: launch_x8<128, 96, 3, 4>(ctx, a, grid); break;
-        case 51: launch_x8<128, 128, 3, 8>(ctx, a, grid); break;
-        case 52: launch_x8<128, 128, 2, 8>(ctx, a, grid); break;
-        case 54: launch_x8<192, 128, 2, 8>(ctx, a, grid); break;
-        case 62: launch_x8<256, 128, 3, 8>(ctx, a, grid); break;
-        case 63: launch_x8<256, 320, 2, 8>(ctx, a, grid); break;
+        case 42: launch_x8<128, 64, 3, 4>(ctx, a, grid, conv); break;
+        case 43: launch_x8<64, 64, 3, 4>(ctx, a, grid, conv); break;
+        case 47: launch_x8<128, 96, 3, 4>(ctx, a, grid, conv); break;
+        case 51: launch_x8<128, 128, 3, 8>(ctx, a, grid, conv); break;
+        case 52: launch_x8<128, 128, 2, 8>(ctx, a, grid, conv); break;
+        case 54: launch_x8<192, 128, 2, 8>(ctx, a, grid, conv); break;
+        case 62: launch_x8<256, 128, 3, 8>(ctx, a, grid, conv); break;
+        case 63: launch_x8<256, 320, 2, 8>(ctx, a, grid, 0); break;
         default: fie_set_error("fie_launch_gemm_x8: tile code %d not built", code); return FIE_EINVAL;
     }
     FIE_LAUNCH_CHECK();

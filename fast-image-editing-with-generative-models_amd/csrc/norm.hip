@@ -28,11 +28,18 @@ struct GnArgsT {
     float eps; int silu;
     float* partial;          // [B][nchunks][G][2]
     float* stats;            // [B][G][2] mean, rstd
+    float o8_inv;            // > 0: Y is e4m3 bytes (value * o8_inv, saturated to +-448): the consumer is an fp8-activation conv (gemm_x8.hip)
     int pg;                  // producer-written partials only (gn_finalize_wide_kernel): slots per granule row; 0 = G.  pg > G: group g is the sum
                              // of the pg / G consecutive slots (4-channel quads) from g * pg / G on -- the 20 / 40-channel groups of the UNet
 };
 
 using GnArgs = GnArgsT<half_t>;
+
+__device__ __forceinline__ int gn_pack4_f8(const float* o, float inv) {
+    auto q = [&](float x) { return fminf(fmaxf(x * inv, -448.f), 448.f); };
+    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q(o[0]), q(o[1]), 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(q(o[2]), q(o[3]), pk, true);
+}
 
 template <typename T>
 __device__ __forceinline__ void gn_load(const GnArgsT<T>& p, int64_t row_global, int c0, float (&x)[8]) {
@@ -228,7 +235,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgsT<T> p) {
             if (p.silu) y = sizeof(T) == 4 ? y / (1.0f + expf(-y)) : fie_silu(y);
             o[j] = y;
         }
-        fie_store8(p.Y + rg * p.C + c0, o);
+        if (p.o8_inv > 0.f)
+            *reinterpret_cast<int2*>(reinterpret_cast<unsigned char*>(p.Y) + rg * p.C + c0) = make_int2(gn_pack4_f8(o, p.o8_inv), gn_pack4_f8(o + 4, p.o8_inv));
+        else
+            fie_store8(p.Y + rg * p.C + c0, o);
     }
 }
 
@@ -333,6 +343,12 @@ __global__ __launch_bounds__(GN1_THREADS) void gn_onepass_kernel(GnArgsT<T> p) {
                 float y = f[j] * sc[j] + sh[j];
                 if (p.silu) y = sizeof(T) == 4 ? y / (1.0f + expf(-y)) : fie_silu(y);
                 f[j] = y;
+            }
+            if (p.o8_inv > 0.f) {                       // e4m3 bytes: V values = V bytes at the same (row, channel) position of a byte tensor
+                unsigned char* d8 = reinterpret_cast<unsigned char*>(p.Y) + ((int64_t)b * p.rows + rsub + (int64_t)i * rstep) * p.C + c0;
+                if constexpr (V == 8) *reinterpret_cast<int2*>(d8) = make_int2(gn_pack4_f8(f, p.o8_inv), gn_pack4_f8(f + 4, p.o8_inv));
+                else *reinterpret_cast<int*>(d8) = gn_pack4_f8(f, p.o8_inv);
+                continue;
             }
             if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -457,7 +473,7 @@ int gn_plan(GnArgsT<T>& p, int C, int G, int64_t rows, int B, int* csplit) {
 
 template <typename T>
 int groupnorm_t(const char* who, fie_ctx* ctx, const void* X1, int C1, const void* X2, int C2, void* Y, int B, int64_t rows_per_image,
-                int groups, const void* gamma, const void* beta, float eps, int silu, void* workspace) {
+                int groups, const void* gamma, const void* beta, float eps, int silu, void* workspace, float o8_inv = 0.f) {
     FIE_REQUIRE(ctx && X1 && Y && gamma && beta && workspace, "%s: NULL argument", who);
     FIE_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0 && (C2 == 0 || X2), "%s: C1=%d C2=%d invalid", who, C1, C2);
     const int C = C1 + C2;
@@ -466,6 +482,7 @@ int groupnorm_t(const char* who, fie_ctx* ctx, const void* X1, int C1, const voi
     p.X1 = (const T*)X1; p.C1 = C1; p.X2 = (const T*)X2; p.C2 = C2; p.Y = (T*)Y;
     p.C = C; p.G = groups; p.cg = C / groups; p.rows = rows_per_image;
     p.gamma = (const T*)gamma; p.beta = (const T*)beta; p.eps = eps; p.silu = silu;
+    p.o8_inv = o8_inv;
     int csplit = 1;
     FIE_REQUIRE(gn_plan(p, C, groups, rows_per_image, B, &csplit) == 0, "%s: cannot split C=%d (groups=%d) into aligned column blocks", who, C, groups);
     if (ctx->gn_onepass && gn_onepass(ctx, p, B)) {
@@ -504,7 +521,7 @@ int layernorm_t(const char* who, fie_ctx* ctx, const void* X, int64_t ldx, void*
 // instead of two.
 template <typename T>
 int groupnorm_stats_t(const char* who, fie_ctx* ctx, const void* X, int C, void* Y, int B, int64_t rows_per_image, int groups, const void* gamma,
-                      const void* beta, float eps, int silu, const void* partial, void* workspace, int partial_groups) {
+                      const void* beta, float eps, int silu, const void* partial, void* workspace, int partial_groups, float o8_inv = 0.f) {
     FIE_REQUIRE(ctx && X && Y && gamma && beta && partial && workspace, "%s: NULL argument", who);
     FIE_REQUIRE(C > 0 && C % 8 == 0 && B > 0 && groups > 0 && C % groups == 0 && rows_per_image > 0 && rows_per_image % 32 == 0,
                 "%s: bad shape C=%d G=%d rows=%lld", who, C, groups, (long long)rows_per_image);
@@ -512,6 +529,7 @@ int groupnorm_stats_t(const char* who, fie_ctx* ctx, const void* X, int C, void*
     p.X1 = (const T*)X; p.C1 = C; p.X2 = nullptr; p.C2 = 0; p.Y = (T*)Y;
     p.C = C; p.G = groups; p.cg = C / groups; p.rows = rows_per_image;
     p.gamma = (const T*)gamma; p.beta = (const T*)beta; p.eps = eps; p.silu = silu;
+    p.o8_inv = o8_inv;
     int csplit = 1;
     FIE_REQUIRE(gn_plan(p, C, groups, rows_per_image, B, &csplit) == 0, "%s: cannot split C=%d (groups=%d) into aligned column blocks", who, C, groups);
     const dim3 grid((unsigned)p.nchunks, (unsigned)B, (unsigned)csplit);
@@ -550,6 +568,21 @@ int fie_groupnorm_stats_nhwc_f16(fie_ctx* ctx, const void* X, int C, void* Y, in
                                  const void* beta, float eps, int silu, const void* partial, void* workspace, int partial_groups) {
     return groupnorm_stats_t<half_t>("fie_groupnorm_stats_nhwc_f16", ctx, X, C, Y, B, rows_per_image, groups, gamma, beta, eps, silu, partial, workspace,
                                      partial_groups);
+}
+
+// GroupNorm (+SiLU) with an e4m3 OUTPUT (BASELINE config 5: the resnet convs read fp8 activations, csrc/gemm_x8.hip): Y8 [B, rows, C] bytes,
+// value * inv_scale saturated to the e4m3 range; otherwise as their f16 twins.
+int fie_groupnorm_nhwc_f16_o8(fie_ctx* ctx, const void* X1, int C1, const void* X2, int C2, void* Y8, int B, int64_t rows_per_image, int groups,
+                              const void* gamma, const void* beta, float eps, int silu, void* workspace, float inv_scale) {
+    FIE_REQUIRE(inv_scale > 0.f, "fie_groupnorm_nhwc_f16_o8: inv_scale must be positive");
+    return groupnorm_t<half_t>("fie_groupnorm_nhwc_f16_o8", ctx, X1, C1, X2, C2, Y8, B, rows_per_image, groups, gamma, beta, eps, silu, workspace, inv_scale);
+}
+
+int fie_groupnorm_stats_nhwc_f16_o8(fie_ctx* ctx, const void* X, int C, void* Y8, int B, int64_t rows_per_image, int groups, const void* gamma,
+                                    const void* beta, float eps, int silu, const void* partial, void* workspace, int partial_groups, float inv_scale) {
+    FIE_REQUIRE(inv_scale > 0.f, "fie_groupnorm_stats_nhwc_f16_o8: inv_scale must be positive");
+    return groupnorm_stats_t<half_t>("fie_groupnorm_stats_nhwc_f16_o8", ctx, X, C, Y8, B, rows_per_image, groups, gamma, beta, eps, silu, partial, workspace,
+                                     partial_groups, inv_scale);
 }
 
 int64_t fie_groupnorm_workspace_bytes(int B, int64_t rows_per_image, int groups) {

@@ -46,6 +46,9 @@ SIGNATURES = {
     "fie_layernorm_f16_o8": [_P, _P, _L, _P, _L, _L, _I, _P, _P, _F, _F],
     "fie_attention_f16_o8": [_P, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I, _F],
     "fie_quantize_f8": [_P, _P, _L, _P, _L, _L, _I, _F],
+    "fie_groupnorm_nhwc_f16_o8": [_P, _P, _I, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _F],
+    "fie_groupnorm_stats_nhwc_f16_o8": [_P, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _P, _I, _F],
+    "fie_conv3x3_x8_nhwc_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _F, _P, _L, _I, _P, _P, _L, _P, _L, _F, _I],
     "fie_attention_f16": [_P, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I],
     "fie_groupnorm_workspace_bytes": [_I, _L, _I],
     "fie_groupnorm_nhwc_f16": [_P, _P, _I, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P],
@@ -510,7 +513,7 @@ class Context:
         return out
 
     def conv3x3(self, x, wp, cout, out=None, stride=1, pad_mode=0, upsample=False, bias=None, rowbias=None,
-                residual=None, scale=1.0, act=ACT_NONE, ldc=None, gn_groups=None):
+                residual=None, scale=1.0, act=ACT_NONE, ldc=None, gn_groups=None, a_scale=1.0):
         """x: [B, H, W, Cin] f16 contiguous NHWC -> [B, OH, OW, ldc]."""
         self.sync_stream()
         self._bind_splitk()
@@ -522,6 +525,14 @@ class Context:
         ldc = ldc or cout
         if out is None:
             out = self._alloc((b, oh, ow, ldc), zero=ldc != cout)
+        if x.dtype == torch.uint8:                      # e4m3 activations from a GroupNorm with out_f8 (fie_conv3x3_x8_nhwc_f16)
+            assert isinstance(wp, W8) and cin % 128 == 0 and wp.stride(0) % 128 == 0
+            tag = self._gn_stats_arm(b * oh * ow, cout, oh * ow, gn_groups) if gn_groups and ldc == cout else None
+            _chk(lib().fie_conv3x3_x8_nhwc_f16(self.h, _p(x), b, h, w, cin, int(upsample), stride, pad_mode, _p(wp.q), wp.stride(0), _p(wp.scale), float(a_scale),
+                                               _p(out), out.stride(2), cout, _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0,
+                                               _p(residual), residual.stride(2) if residual is not None else 0, float(scale), act))
+            out._gn_tag = tag
+            return out
         if isinstance(wp, W8):
             _chk(lib().fie_conv3x3_w8_nhwc_f16(self.h, _p(x), b, h, w, cin, int(upsample), stride, pad_mode, _p(wp.q), wp.stride(0),
                                                _p(wp.scale), _p(out), out.stride(2), cout, _p(bias), _p(rowbias),
@@ -563,14 +574,14 @@ class Context:
                                      out.stride(0), batch, heads, tq, tk, head_dim, float(scale), int(causal)))
         return out
 
-    def groupnorm(self, x1, gamma, beta, groups, eps, silu, x2=None, out=None):
-        """x1: [B, rows, C1] (+ x2: [B, rows, C2]) NHWC-flattened, contiguous -> [B, rows, C1+C2]."""
+    def groupnorm(self, x1, gamma, beta, groups, eps, silu, x2=None, out=None, out_f8=False, out_inv_scale=1.0):
+        """x1: [B, rows, C1] (+ x2: [B, rows, C2]) NHWC-flattened, contiguous -> [B, rows, C1+C2] (out_f8: as e4m3 bytes, value * out_inv_scale)."""
         self.sync_stream()
         b, rows, c1 = x1.shape[0], x1[0].numel() // x1.shape[-1], x1.shape[-1]
         c2 = x2.shape[-1] if x2 is not None else 0
         assert x1.is_contiguous() and (x2 is None or x2.is_contiguous())
         if out is None:
-            out = self._alloc(x1.shape[:-1] + (c1 + c2,))
+            out = self._alloc(x1.shape[:-1] + (c1 + c2,), torch.uint8 if out_f8 else None)
         need = lib().fie_groupnorm_workspace_bytes(b, rows, groups)
         key = (self._stream, self.ws_tag)            # one scratch buffer per stream (and per in-flight graph slot)
         ws = self._gn_ws.get(key)
@@ -581,8 +592,16 @@ class Context:
         tag = getattr(x1, "_gn_tag", None)
         if (tag is not None and x2 is None and tag[1:5] == (groups, c1, rows, b) and tag[5] == self._gn_gen and tag[6] == key):
             # the producer's epilogue left this tensor's partial sums (and nothing has overwritten them): one read of x instead of two
+            if out_f8:
+                _chk(lib().fie_groupnorm_stats_nhwc_f16_o8(self.h, _p(x1), c1, _p(out), b, rows, groups, _p(gamma), _p(beta), float(eps), int(silu),
+                                                           _p(tag[0]), _p(ws), tag[7], float(out_inv_scale)))
+                return out
             _chk(lib().fie_groupnorm_stats_nhwc_f16(self.h, _p(x1), c1, _p(out), b, rows, groups, _p(gamma), _p(beta), float(eps), int(silu),
                                                     _p(tag[0]), _p(ws), tag[7]))
+            return out
+        if out_f8:
+            _chk(lib().fie_groupnorm_nhwc_f16_o8(self.h, _p(x1), c1, _p(x2), c2, _p(out), b, rows, groups, _p(gamma), _p(beta), float(eps), int(silu), _p(ws),
+                                                 float(out_inv_scale)))
             return out
         _chk((lib().fie_groupnorm_nhwc_f32 if self.f32 else lib().fie_groupnorm_nhwc_f16)(self.h, _p(x1), c1, _p(x2), c2, _p(out), b, rows, groups, _p(gamma),
                                           _p(beta), float(eps), int(silu), _p(ws)))

@@ -54,9 +54,13 @@ class Conv3:
         self.cin_pad = cin_pad or (self.cin + 7) // 8 * 8
         self.ldc = cout_pad or self.cout
         self.n = (self.cout + 3) // 4 * 4          # kernel writes whole 4-channel groups (extra ones are zeros)
-        # fp8-weight models (config 5): the 1280-wide convs of the 32x32-latent level stay fp16 -- M = 2048 rows fill the chip only with split-K, which
-        # the fp16 ring kernels have and the fp8-weight conv kernel has not (79 vs 109 us for 1280 -> 1280, profiles/r03_per_shape_roofline_fp8.md)
-        self.wp = ctx.pack_conv3x3(w, self.cin_pad, quant=self.cout < 1280)
+        # fp8-weight models (config 5).  A conv whose input comes from a GroupNorm and has Cin % 128 == 0 can read e4m3 ACTIVATIONS (csrc/gemm_x8.hip,
+        # conv view, split-K included).  The other 1280-wide convs of the 32x32-latent level stay fp16: M = 2048 rows fill the chip only with split-K,
+        # which the fp16 ring kernels have and the fp8-weight / fp16-activation conv kernel has not (79 vs 109 us for 1280 -> 1280)
+        a8_ok = bool(ctx.w8 and ctx.a8 and getattr(ctx, "a8_conv", True) and self.cin_pad == self.cin and self.cin % 128 == 0
+                     and name.endswith((".conv1", ".conv2")))                # the resnet convs: their input is a GroupNorm output
+        self.wp = ctx.pack_conv3x3(w, self.cin_pad, quant=self.cout < 1280 or a8_ok)
+        self.a8 = a8_ok and isinstance(self.wp, hip.W8) and self.wp.stride(0) % 128 == 0      # the caller hands in e4m3 (GroupNorm with out_f8)
         # up-sampler convs (diffusers: "...upsamplers.0.conv") run as four 2x2 parity convs (hip.py: pack_conv_up2x).  Packed HERE, not at
         # the first call: a first call inside a launch-program recording would record the pack launches instead of running them.
         self.wp4 = None
@@ -101,10 +105,10 @@ class Resnet:
 
     def __call__(self, ctx, x, temb_all=None, skip=None):
         b, h, w, _ = x.shape
-        y = ctx.groupnorm(x, self.n1.g, self.n1.b, self.groups, self.eps, True, x2=skip)
+        y = ctx.groupnorm(x, self.n1.g, self.n1.b, self.groups, self.eps, True, x2=skip, out_f8=self.c1.a8)      # fp8 model: e4m3 for an fp8-activation conv
         rb = temb_all[:, self.temb_slot[0]:self.temb_slot[1]] if self.temb_slot is not None else None
         y = self.c1(ctx, y, rowbias=rb, gn_groups=self.groups)          # norm2's first pass rides on conv1's epilogue where the group width allows
-        y = ctx.groupnorm(y, self.n2.g, self.n2.b, self.groups, self.eps, True)
+        y = ctx.groupnorm(y, self.n2.g, self.n2.b, self.groups, self.eps, True, out_f8=self.c2.a8 and self.wp_plus is None)
         if self.wp_plus is not None and ctx.conv_plus_shortcut and x.shape[-1] % 64 == 0 and (skip is None or skip.shape[-1] % 64 == 0):
             return ctx.conv3x3_plus(y, self.wp_plus, self.c2.n, x.view(b * h * w, -1), None if skip is None else skip.view(b * h * w, -1),
                                     bias=self.b_plus, gn_groups=self.groups)

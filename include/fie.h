@@ -219,6 +219,17 @@ int fie_layernorm_f16_o8(fie_ctx* ctx, const void* X, int64_t ldx, void* Y8, int
 int fie_attention_f16_o8(fie_ctx* ctx, const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O8, int64_t ldo8,
                          int B, int H, int Tq, int Tk, int D, float scale, int causal, float inv_scale);
 int fie_quantize_f8(fie_ctx* ctx, const void* X, int64_t ldx, void* Y8, int64_t ldy, int64_t rows, int C, float inv_scale);
+/* The resnet convs of an fp8 model (upstream resnet.py: GroupNorm -> SiLU -> conv): GroupNorm writes e4m3 (the _o8 twins of fie_groupnorm_nhwc_f16 /
+ * fie_groupnorm_stats_nhwc_f16; Y8 = [B, rows, C] bytes) and fie_conv3x3_x8_nhwc_f16 runs the conv view of the same block-scaled MFMA kernel: X8 NHWC
+ * e4m3 with Cin % 128 == 0 (a K-step is 128 channels of one tap), W8packed from fie_pack_conv3x3_f8 with cin_pad == Cin; output f16.  Conv + 1x1 side
+ * inputs and the 2x2 parity up-samplers have no fp8-activation form (their other inputs are the fp16 residual stream). */
+int fie_groupnorm_nhwc_f16_o8(fie_ctx* ctx, const void* X1, int C1, const void* X2, int C2, void* Y8, int B, int64_t rows_per_image, int groups,
+                              const void* gamma, const void* beta, float eps, int silu, void* workspace, float inv_scale);
+int fie_groupnorm_stats_nhwc_f16_o8(fie_ctx* ctx, const void* X, int C, void* Y8, int B, int64_t rows_per_image, int groups, const void* gamma,
+                                    const void* beta, float eps, int silu, const void* partial, void* workspace, int partial_groups, float inv_scale);
+int fie_conv3x3_x8_nhwc_f16(fie_ctx* ctx, const void* X8, int B, int H, int W, int Cin, int upsample2x, int stride, int pad_mode, const void* W8packed,
+                            int64_t ldw, const float* w_scale, float a_scale, void* Y, int64_t ldc, int Cout, const void* bias, const void* rowbias,
+                            int64_t ld_rowbias, const void* residual, int64_t ldr, float scale, int act);
 
 /* ---- fp32 path (`FastEditor(use_full_precision=True)`, run_batch.py --full_precision / --quality_mode; reference:
  * src/pipeline.py:67-71,94-99).  Same graphs, fp32 storage, exact fp32 arithmetic on v_mfma_f32_16x16x4_f32.

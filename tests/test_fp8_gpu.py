@@ -227,6 +227,63 @@ def test_fp8_producers_layernorm_and_attention(fie):
     assert (o8.view(torch.float8_e4m3fn).float().cpu() == want).float().mean() > 0.98
 
 
+@pytest.mark.parametrize("code", [0, 42, 43, 47, 51, 52, 54, 62, 30062, 20051])
+def test_conv_x8_fp8_activations_matches_quantised_reference(fie8, code):
+    """fie_conv3x3_x8_nhwc_f16 (conv view of csrc/gemm_x8.hip): e4m3 NHWC activations (Cin % 128 == 0, a K-step = 128 channels of one tap) x e4m3
+    weights, against F.conv2d on the SAME quantised operands: stride 1 / 2, the VAE-style asymmetric pad, fused nearest-2x upsampling, ragged
+    sizes, bias + row bias + SiLU + residual, split-K (slices that start in the middle of a tap)."""
+    from fie_amd import hip
+    fie8.force_tile(code)
+    for b, h, w_, cin, cout, stride, pad_mode, ups in [(2, 32, 32, 128, 128, 1, 0, False), (2, 32, 32, 1280, 1280, 1, 0, False), (1, 32, 32, 256, 64, 2, 1, False),
+                                                       (1, 16, 16, 128, 192, 1, 0, True), (1, 9, 7, 384, 64, 1, 0, False), (2, 20, 20, 256, 320, 2, 0, False)]:
+        x = rnd(b, h, w_, cin, seed=1, scale=2.0)
+        wt = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+        wp = fie8.pack_conv3x3(wt.to(DEV))
+        assert isinstance(wp, hip.W8) and wp.stride(0) % 128 == 0
+        x8 = fie8.quantize_f8(x.view(-1, cin).to(DEV), 0.5).view(b, h, w_, cin)
+        xq = x8.view(torch.float8_e4m3fn).float().cpu().permute(0, 3, 1, 2)
+        bias = rnd(cout, seed=3)
+        oh = ((h << ups) + (2 if pad_mode == 0 else 1) - 3) // stride + 1
+        ow = ((w_ << ups) + (2 if pad_mode == 0 else 1) - 3) // stride + 1
+        res, rb = rnd(b, oh, ow, cout, seed=4), rnd(b, cout, seed=5)
+        out = fie8.conv3x3(x8, wp, cout, stride=stride, pad_mode=pad_mode, upsample=ups, bias=bias.to(DEV), rowbias=rb.to(DEV), residual=res.to(DEV),
+                           act=hip.ACT_SILU, a_scale=2.0)
+        assert "fp8 activations" in hip.last_gemm_kernel(fie8), hip.last_gemm_kernel(fie8)
+        wq = wp.q.view(torch.float8_e4m3fn).float().cpu()[:cout, :9 * cin].reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+        xi = xq
+        if ups:
+            xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+        if pad_mode == 1:
+            xi = F.pad(xi, (0, 1, 0, 1))
+        lin = F.conv2d(xi, wq, None, stride=stride, padding=1 if pad_mode == 0 else 0) * 2.0 * wp.scale[:cout].cpu()[None, :, None, None]
+        ref = F.silu(lin + bias.float()[None, :, None, None] + rb.float()[:, :, None, None]) + res.float().permute(0, 3, 1, 2)
+        assert rel_err(out.permute(0, 3, 1, 2), ref) < 2e-3, (b, h, w_, cin, cout, stride, pad_mode, ups)
+
+
+def test_groupnorm_with_e4m3_output(fie):
+    """GroupNorm (+SiLU) writing e4m3 for an fp8-activation conv: the single-pass kernel (small maps), the three-kernel path, two-source input
+    (the decoder's concat) and the statistics-from-the-epilogue path, each against its own fp16 output converted with saturating RNE."""
+    g = torch.Generator().manual_seed(9)
+    for b, hh, c1, c2 in [(2, 32, 1280, 0), (2, 64, 640, 0), (2, 32, 1280, 1280), (1, 64, 640, 320)]:
+        x1 = torch.randn(b, hh, hh, c1, generator=g).half().to(DEV)
+        x2 = torch.randn(b, hh, hh, c2, generator=g).half().to(DEV) if c2 else None
+        gam, bet = (1 + 0.2 * torch.randn(c1 + c2, generator=g)).half().to(DEV), (0.1 * torch.randn(c1 + c2, generator=g)).half().to(DEV)
+        y16 = fie.groupnorm(x1, gam, bet, 32, 1e-5, True, x2=x2)
+        y8 = fie.groupnorm(x1, gam, bet, 32, 1e-5, True, x2=x2, out_f8=True, out_inv_scale=2.0)
+        assert y8.dtype == torch.uint8 and y8.shape == y16.shape
+        got, want = y8.view(torch.float8_e4m3fn).float().cpu(), q8(y16.float().cpu() * 2.0)
+        assert (got == want).float().mean() > 0.98 and rel_err(got, want) < 0.13, (b, hh, c1, c2)
+    # statistics from the producing conv's epilogue (quad partials: 640 channels = 20 per group)
+    x = rnd(2, 64, 64, 128, seed=1).to(DEV)
+    wc = fie.pack_conv3x3(rnd(640, 128, 3, 3, seed=2, scale=(9 * 128) ** -0.5).to(DEV))
+    gam, bet = torch.ones(640, dtype=torch.float16, device=DEV), torch.zeros(640, dtype=torch.float16, device=DEV)
+    y = fie.conv3x3(x, wc, 640, gn_groups=32)
+    assert y._gn_tag is not None
+    y8 = fie.groupnorm(y, gam, bet, 32, 1e-5, True, out_f8=True)
+    want = q8(fie.groupnorm(y.clone(), gam, bet, 32, 1e-5, True).float().cpu())
+    assert (y8.view(torch.float8_e4m3fn).float().cpu() == want).float().mean() > 0.98
+
+
 def test_fp8_activation_block_matches_the_fp16_activation_block(fie):
     """One BasicTransformerBlock at the real width (2 x 1024 tokens x 1280) with fp8 weights: the fp8-ACTIVATION flow (producers write e4m3,
     block-scaled MFMA) against the round-2 flow (fp16 activations converted per fragment inside the GEMM).  Both multiply the same e4m3

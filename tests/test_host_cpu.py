@@ -1,5 +1,6 @@
 """Host logic of run_batch.py without a GPU: the per-image loop, --batch_size grouping, --in_flight worker threads, per-image
 failure isolation (reference run_batch.py:176-261) -- driven through a stub editor."""
+import os
 import threading
 
 import numpy as np
@@ -7,6 +8,8 @@ import pytest
 from PIL import Image
 
 import run_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class StubEditor:
@@ -111,7 +114,9 @@ def test_bench_reads_the_pmc_record_of_the_tile_it_ran(tmp_path):
     import bench
     name = "gemm3_kernel<192x128> (gemm, tile code 54) (FF1 GEGLU projection, 32x32 latents)"
     mb, src = bench.pmc_traffic(name, 2048, 10240, 1280)
-    assert mb is not None and 50 < mb < 400 and src and all("counter_collection" in s for s in src)
+    assert mb is not None and 50 < mb < 400 and src and all(s.startswith("profiles/r03_ff1_pmc_raw/") and os.path.exists(os.path.join(ROOT, s)) for s in src)
+    mb63, _ = bench.pmc_traffic(name.replace("<192x128>", "<256x320>").replace("code 54", "code 63"), 2048, 10240, 1280)    # round 3's exact-fit tile
+    assert mb63 is not None and 50 < mb63 < mb
     assert bench.pmc_traffic(name.replace("code 54", "code 43"), 2048, 10240, 1280) == (None, None)
     assert bench.pmc_traffic(name, 4096, 10240, 1280) == (None, None)
     assert bench.pmc_traffic("gemm3w8_kernel<128x128> (gemm, fp8 weights, tile code 54)", 2048, 10240, 1280) == (None, None)
