@@ -25,6 +25,10 @@ SIGNATURES = {
     "fie_ctx_set_stream": [_P, _P],
     "fie_ctx_error_flag": [_P, _P],
     "fie_ctx_destroy": [_P],
+    "fie_weights_register": [_P, _c.c_char_p, _P, _L, _L],
+    "fie_weights_clear": [_P],
+    "fie_vae_decode_workspace_bytes": [_P, _I, _I],
+    "fie_vae_decode_f16": [_P, _P, _P, _P, _P, _L],
     "fie_program_begin": [_P, _c.POINTER(_P)],
     "fie_program_end": [_P],
     "fie_program_launches": [_P],
@@ -124,7 +128,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.argtypes = args
-            fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes", "fie_time_embed_workspace_bytes", "fie_gn_stats_bytes", "fie_debug_oplog_read") else _I
+            fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes", "fie_time_embed_workspace_bytes", "fie_gn_stats_bytes", "fie_debug_oplog_read", "fie_vae_decode_workspace_bytes") else _I
         _lib.fie_last_error.restype = ctypes.c_char_p
         _lib.fie_last_error.argtypes = []
         _lib.fie_debug_last_gemm_kernel.restype = ctypes.c_char_p
@@ -151,6 +155,12 @@ def _p(t):
 
 
 GRAPH_NAMES = ("unet_forward", "controlnet_forward", "vae_encode", "vae_decode", "clip_text_forward")
+
+
+class VaeConfig(ctypes.Structure):
+    """include/fie.h: fie_vae_config (the C++ decoder walk, csrc/graphs.cpp)."""
+    _fields_ = [("latent_h", _I), ("latent_w", _I), ("num_blocks", _I), ("block_out_channels", _I * 8), ("layers_per_block", _I),
+                ("norm_num_groups", _I), ("norm_eps", _F), ("out_channels", _I)]
 
 
 class Program:

@@ -65,10 +65,36 @@ int fie_ctx_destroy(fie_ctx* ctx);
  * What these entries are NOT: a C++ implementation of the model graphs.  The graph logic (which layer follows which, the shapes, the
  * weight packing) lives in the Python host code (fie_amd/nn.py, vae.py, clip.py); a named entry is a REPLAY HANDLE for a launch list that
  * walk recorded, with every pointer frozen in.  A non-Python host therefore cannot reach fie_unet_forward without first driving the op
- * entries below in graph order itself (there is no fie_weights_register: the op entries take weight pointers per call).  The product
+ * entries below in graph order itself (fie_vae_decode_f16 above is the one graph that IS walked in C++; for the others the op entries take weight
+ * pointers per call).  The product
  * path (hipGraph replay of the Python walk) does not go through these entries; tests/test_programs_gpu.py does.
  *   fie_graph_register binds a program to one of the names "unet_forward", "controlnet_forward", "vae_encode", "vae_decode",
  *   "clip_text_forward"; the five named entries run the program bound to their name (FIE_EINVAL if none). */
+/* ---- A graph-level forward that IS a forward (round 3): the AutoencoderKL decoder (upstream models/autoencoders/vae.py Decoder behind
+ * AutoencoderKL.decode, the last model call of the pipeline call at /root/reference/src/pipeline.py:261-272) sequenced in C++ over the op entries
+ * below (csrc/graphs.cpp), on weights registered once by their diffusers parameter names -- tensor arguments in and out, no Python graph code, no
+ * recorded launch list.
+ *   fie_weights_register(name, ptr, n, ld): "<conv>.weight" = fie_pack_conv3x3_f16 output (n = Cout, ld = ldw), "<linear>.weight" =
+ *     fie_pack_rows_f16 output, biases / norm gains as plain f16 vectors (ld = 0); the mid-block attention's q | k | v as ONE packed matrix
+ *     "decoder.mid_block.attentions.0.to_qkv.{weight,bias}"; "post_quant_conv.{weight,bias}" zero-padded to the 8-channel latent layout.
+ *   fie_vae_decode_f16: z = [1, latent_h, latent_w, 8] f16 (latents / scaling_factor, 4 real channels) -> out = [1, 8 h, 8 w, 4] f16 (3 real
+ *     channels); workspace >= fie_vae_decode_workspace_bytes (five rotating activation buffers + GroupNorm scratch).  Asynchronous on the ctx
+ *     stream, hipGraph-capturable.  Same kernels and order as the Python walk (fie_amd/vae.py) apart from two fusions it does not take (GroupNorm
+ *     sums from the producing epilogue, 2x2-parity up-samplers): results agree to rounding. */
+typedef struct fie_vae_config {
+    int latent_h, latent_w;
+    int num_blocks;                /* len(block_out_channels), <= 8 */
+    int block_out_channels[8];     /* encoder order, e.g. 128, 256, 512, 512 */
+    int layers_per_block;          /* 2: the decoder runs layers_per_block + 1 resnets per up block */
+    int norm_num_groups;           /* 32 */
+    float norm_eps;                /* 1e-6 */
+    int out_channels;              /* 3 */
+} fie_vae_config;
+int fie_weights_register(fie_ctx* ctx, const char* name, const void* ptr, int64_t n, int64_t ld);
+int fie_weights_clear(fie_ctx* ctx);
+int64_t fie_vae_decode_workspace_bytes(const fie_vae_config* cfg, int latent_h, int latent_w);
+int fie_vae_decode_f16(fie_ctx* ctx, const fie_vae_config* cfg, const void* z, void* out, void* workspace, int64_t workspace_bytes);
+
 typedef struct fie_program fie_program;
 int fie_program_begin(fie_ctx* ctx, fie_program** out);
 int fie_program_end(fie_ctx* ctx);

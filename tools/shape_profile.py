@@ -44,11 +44,14 @@ def run(out_path, model="ssd-1b"):
     ctx.autotune(2 if pipe.autotune else 0)
     pipe.run_device(job)
     torch.cuda.synchronize()
+    if os.environ.get("FIE_PROFILE_PROBE"):      # timing-only probes of the LDS-DMA GEMM / conv kernels (include/fie.h: fie_debug_gemm_probe; outputs are wrong):
+        ctx.gemm_probe(int(os.environ["FIE_PROFILE_PROBE"]))      # 2 = every tile fetches tile (0,0)'s operands: the in-network times with all operand loads hitting L2
     ctx.oplog(True)
     pipe.run_device(job)
     torch.cuda.synchronize()
     lines = ctx.oplog_read()
     ctx.oplog(False)
+    ctx.gemm_probe(0)
     os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     with open(out_path, "w") as f:
         f.write("\n".join(lines) + "\n")
