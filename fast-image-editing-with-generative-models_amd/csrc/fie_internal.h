@@ -52,6 +52,7 @@ struct fie_ctx {
     // tuning / test hooks of the GEMM launch table (fie_debug_*): per ctx, never process-global
     int force_tile = 0;
     int gemm_probe = 0;
+    int epi_prefetch = 1;                       // ring kernels load the epilogue's bias / residual operands before the K loop (A/B switch: fie_debug_epilogue_prefetch)
     unsigned* gemm_stamps = nullptr;
     float* gn_target = nullptr;              // fie_gn_stats_target: consumed by the next GEMM / conv launch
     int64_t gn_target_rows = 0;

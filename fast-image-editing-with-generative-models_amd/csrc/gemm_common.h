@@ -40,6 +40,7 @@ struct GemmArgs {
     float* gn_partial; int gn_rows, gn_G, gn_cg;   // GroupNorm statistics of the OUTPUT (fie_gn_stats_target): per image and 32-row granule [b][gn_rows / 32][gn_G][2] = (sum, sum of squares) of the f16-rounded values, gn_cg = N / gn_G in {4, 8, 16} channels per group; NULL: none
     const float* w_scale;                   // fp8 weights (gemm_w8.hip): per-output-channel dequantisation scale [N], applied to the accumulator first; Wt then points at e4m3 bytes and ldw counts bytes
     unsigned* stamps;                       // tile codes 97 / 98: [tile][wave][8] cycle sums of the K-loop segments (fie_debug_gemm_stamps), else NULL
+    int epi_prefetch;                       // ring kernels: bias row + residual tile loaded ahead of the K loop (EpiPre below); 0 = in the epilogue (fie_debug_epilogue_prefetch)
     int probe;                              // timing-only probes (fie_debug_gemm_probe; outputs are wrong): 1 = every DMA load dropped (zero-record descriptors), 2 = every tile fetches tile (0,0)'s operands (all L2 hits), 3 = ring kernels issue no DMA inside the K loop (MFMA + ds_read + barrier floor), 4 = no epilogue (nothing stored)
     // split-K (ring kernels, fie_splitk_workspace): the K-steps of a tile are dealt to `splitk` consecutive blocks (one XCD under the remap); each
     // writes its fp32 partial tile to sk_slabs[tile][slice] (write-through), draws a ticket from sk_tickets[tile]; the block that draws the last
@@ -85,9 +86,45 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int FM, int FN, int WM, int WN, bool BUF = false>
-__device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane) {
+// The epilogue's operands that do not depend on the accumulators (bias row, residual tile), loaded BEFORE the K loop: after it they are a
+// cold HBM / L2 miss of 1-2 us on the critical path of a 15-20 us kernel (round 3, tools/fit_probe.py: 6 us of a K = 1280 projection's
+// 15 us do not scale with K).  16-36 VGPRs, which the LDS-limited ring kernels have to spare.  Same lane mapping and range checks as the
+// epilogue below (out-of-range lanes read zero through the descriptor).
+template <int FM, int FN>
+struct EpiPre {
+    u32x2 bias[FN];
+    u32x2 res[FM][FN];
+    bool on;
+};
+template <int FM, int FN, int WM, int WN>
+__device__ __forceinline__ void epilogue_prefetch(const GemmArgs& p, EpiPre<FM, FN>& pre, int m0, int n0, int wm, int wn, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
+    const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
+    pre.on = true;
+    if (p.bias) {
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.bias), 0, p.N * 2, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) pre.bias[i] = __builtin_amdgcn_raw_buffer_load_b64(rb, (unsigned)(ncol + i * 16) * 2u, 0, 0);
+    }
+    if (p.res) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.res), 0, (int)(((int64_t)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = mrow + j * 16;
+            const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldr * 2u : 0x80000000u;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int n = ncol + i * 16;
+                pre.res[j][i] = __builtin_amdgcn_raw_buffer_load_b64(rs, ro + (n < p.N ? (unsigned)n << 1 : 0xC0000000u), 0, 0);
+            }
+        }
+    }
+}
+
+template <int FM, int FN, int WM, int WN, bool BUF = false>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane, const EpiPre<FM, FN>* pre = nullptr) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool have_pre = pre != nullptr && pre->on;
     if (p.probe == 4 && p.M > 0) return;                    // timing probe: no epilogue at all (p.M > 0 keeps the accumulators live)
     const bool geglu = p.act == FIE_ACT_GEGLU;
     const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
@@ -120,7 +157,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
     if (p.bias) {
         f16x4 b[FN];
 #pragma unroll
-        for (int i = 0; i < FN; ++i) b[i] = *reinterpret_cast<const f16x4*>(p.bias + col(i));
+        for (int i = 0; i < FN; ++i) b[i] = have_pre ? as_h4(pre->bias[i]) : *reinterpret_cast<const f16x4*>(p.bias + col(i));
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -166,7 +203,10 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
             f16x4 b[FN];
-            if constexpr (BUF) {
+            if (have_pre) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i) b[i] = as_h4(pre->res[j][i]);
+            } else if constexpr (BUF) {
                 const unsigned ro = roff(j, p.ldr);
 #pragma unroll
                 for (int i = 0; i < FN; ++i) b[i] = as_h4(__builtin_amdgcn_raw_buffer_load_b64(rs, ro + coff(i, false), 0, 0));

@@ -301,6 +301,13 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // bias row + residual tile go out ahead of the ring's first stage and are complete (loads return in order) by the first counted wait
+    EpiPre<FM, FN> pre;
+    pre.on = false;
+    if constexpr (FM * FN <= 16) {
+        if (nsplit == 1 && p.epi_prefetch) epilogue_prefetch<FM, FN, WM, WN>(p, pre, m0, n0, wm, wn, lane);
+    }
+
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
         if (s < nk) { issue(kbeg + s, s); issue_w(kbeg + s, s); }
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         if constexpr (FN & 1)
             epilogue<FM, 1, WM, WN, true>(p, reinterpret_cast<f32x4(&)[1][FM]>(acc[FN - 1]), m0, n0 + 16 * (FN - 1), wm, wn, lane);
     } else {
-        epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane);
+        epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane, &pre);
     }
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's stores have left the wave
@@ -585,6 +592,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     a.sk_slabs = reinterpret_cast<float*>(static_cast<char*>(ctx->sk_ws) + kSkTickets * 4);
     a.order = order;
     a.probe = ctx->gemm_probe;
+    a.epi_prefetch = ctx->epi_prefetch;
     a.stamps = (code == 97 || code == 98 || code == 94) ? ctx->gemm_stamps : nullptr;
     snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 90 ? "gemm3_kernel+prefetch" : code >= 80 ? "gemm8_kernel" : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
              t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
@@ -867,6 +875,12 @@ int fie_debug_tile_override(fie_ctx* ctx, const char* spec) {
 int fie_debug_gemm_probe(fie_ctx* ctx, int mode) {
     FIE_REQUIRE(ctx != nullptr && mode >= 0 && mode <= 4, "fie_debug_gemm_probe: bad argument");
     ctx->gemm_probe = mode;
+    return FIE_OK;
+}
+
+int fie_debug_epilogue_prefetch(fie_ctx* ctx, int on) {
+    FIE_REQUIRE(ctx != nullptr, "fie_debug_epilogue_prefetch: ctx is NULL");
+    ctx->epi_prefetch = on ? 1 : 0;
     return FIE_OK;
 }
 

@@ -97,6 +97,7 @@ SIGNATURES = {
     "fie_gemm_autotune_report": [_P, ctypes.c_char_p, _I],
     "fie_debug_tune_exclude": [_P, ctypes.c_char_p],
     "fie_debug_gemm_probe": [_P, _I],
+    "fie_debug_epilogue_prefetch": [_P, _I],
     "fie_debug_gemm_stamps": [_P, _P],
     "fie_splitk_workspace": [_P, _P, _L],
     "fie_debug_splitk": [_P, _I],
@@ -230,6 +231,7 @@ class Context:
         self.splitk_bytes = int(os.environ.get("FIE_SPLITK_MB", "96")) << 20      # 0: never split K
         self.gn_from_epilogue = os.environ.get("FIE_GN_FROM_EPILOGUE", "1") != "0"
         self.gn_quads = os.environ.get("FIE_GN_QUADS", "1") != "0"      # ... also for the UNet's 20 / 40-channel groups (quad partials); A/B switch
+        self._epi_prefetch = True                 # C side default (fie_debug_epilogue_prefetch)
         self.up2x_parity = os.environ.get("FIE_UP2X_PARITY", "1") != "0"
         self.conv_plus_shortcut = os.environ.get("FIE_CONV_PLUS", "1") != "0"   # resnet conv2 + 1x1 shortcut as one GEMM (fie_conv3x3_plus_nhwc_f16)      # 2x-upsampling convs as four 2x2 convs (fie_conv_up2x_nhwc_f16)
         self._resize_tables = {}       # (in, out) -> (taps, bounds, ksize) of the LANCZOS resample, on the device
@@ -356,6 +358,16 @@ class Context:
     def gemm_probe(self, mode):
         """TIMING-ONLY probes of the LDS-DMA GEMM kernels (outputs are wrong): 0 off, 1 loads dropped, 2 all tiles load tile (0,0)."""
         _chk(lib().fie_debug_gemm_probe(self.h, int(mode)))
+
+    @property
+    def epi_prefetch(self):
+        return self._epi_prefetch
+
+    @epi_prefetch.setter
+    def epi_prefetch(self, on):
+        """A/B switch: bias row / residual tile of the ring GEMM and conv kernels loaded ahead of the K loop (default) or in the epilogue."""
+        _chk(lib().fie_debug_epilogue_prefetch(self.h, int(bool(on))))
+        self._epi_prefetch = bool(on)
 
     def tile_override(self, spec):
         """"mode,M,N,K=code;..." per-shape tile codes (None clears).  Returns the number of entries parsed."""

@@ -353,6 +353,7 @@ int fie_gemm_autotune(fie_ctx* ctx, int on);
 int fie_gemm_autotune_report(fie_ctx* ctx, char* buf, int cap);
 int fie_debug_tune_exclude(fie_ctx* ctx, const char* codes);        /* A/B hook (tools/tuner_ab.py): comma-separated tile codes the tuner must not offer (10000 = every split-K variant; NULL / "" = none); forgets every remembered choice; returns the number of codes parsed */
 int fie_debug_gemm_probe(fie_ctx* ctx, int mode);                  /* TIMING-ONLY probes of the LDS-DMA kernels (outputs are wrong): 0 off, 1 = DMA loads dropped by the descriptor, 2 = every tile loads tile (0,0), 3 = ring kernels: no DMA issued in the K loop, 4 = no epilogue */
+int fie_debug_epilogue_prefetch(fie_ctx* ctx, int on);            /* A/B switch (default on): the ring GEMM / conv kernels load the bias row and the residual tile BEFORE the K loop; results are identical either way */
 int fie_debug_gemm_stamps(fie_ctx* ctx, void* buf);                  /* device buffer for the stamped ring kernels (tile codes 97 / 98): per tile and wave 8 uint32 cycle sums -- [0] drain + barrier, [1]/[4] DMA issue, [2]/[5] fragment reads, [3]/[6] MFMA issue (code 98: [0] = whole K-steps); NULL detaches */
 const char* fie_debug_last_gemm_kernel(fie_ctx* ctx);              /* kernel / tile of the last fie_gemm_f16 / fie_conv3x3_nhwc_f16 launch */
 int fie_debug_oplog(fie_ctx* ctx, int on);                         /* launch log for the per-shape profile (tools/shape_profile.py): while on, every launch appends "kernel symbol|blocks|threads|LDS bytes|op description (shape, tile code, algorithmic flop / bytes)" */

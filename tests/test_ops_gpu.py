@@ -338,6 +338,32 @@ def test_gemm_view_only_tiles(fie, code):
         fie.force_tile(0)
 
 
+@pytest.mark.parametrize("code", [42, 43, 44, 47, 51, 52, 54, 62, 95, 96])
+def test_epilogue_operands_loaded_ahead_of_the_k_loop(fie, code):
+    """Ring kernels read the bias row and the residual tile BEFORE the K loop (gemm_common.h: EpiPre; round 3).  Same values, same
+    arithmetic: bit-identical to the in-epilogue loads (fie_debug_epilogue_prefetch 0), ragged edges and an in-place residual included,
+    for the GEMM and the conv view of every ring tile."""
+    try:
+        fie.force_tile(code)
+        for m, n, k in [(2048, 1280, 1280), (300, 328, 200), (77, 960, 2048)]:
+            a, w, bias, res = rnd(m, k, seed=m).to(DEV), fie.pack_linear(rnd(n, k, seed=n, scale=k ** -0.5).to(DEV)), rnd(n, seed=3).to(DEV), rnd(m, n, seed=4)
+            outs = []
+            for pre in (False, True):
+                fie.epi_prefetch = pre
+                inplace = res.to(DEV).clone()
+                outs.append(fie.gemm(a, w, n, bias=bias, residual=inplace, out=inplace).clone())
+            assert torch.equal(outs[0], outs[1]), (code, m, n, k)
+        x, wc, bias, res = rnd(2, 24, 20, 128, seed=5).to(DEV), fie.pack_conv3x3(rnd(192, 128, 3, 3, seed=6, scale=1152 ** -0.5).to(DEV)), rnd(192, seed=7).to(DEV), rnd(2, 24, 20, 192, seed=8).to(DEV)
+        outs = []
+        for pre in (False, True):
+            fie.epi_prefetch = pre
+            outs.append(fie.conv3x3(x, wc, 192, bias=bias, residual=res).clone())
+        assert torch.equal(outs[0], outs[1]), code
+    finally:
+        fie.epi_prefetch = True
+        fie.force_tile(0)
+
+
 def test_phased_256x256_kernel_large_and_odd_ktiles(fie):
     """gemm8_kernel (tile code 81) at the sizes it is selected for, against the ring kernel and fp32 torch: K-tile counts 1, 2,
     3 (odd: the buffer-parity tail), 20 and 64; epilogues (bias, row bias, SiLU, GEGLU, scale + residual); conv with tap

@@ -1,5 +1,6 @@
 """Whole-edit (hipGraph replay) A/B of one boolean switch of the HIP context, one process, alternating captures (a captured graph keeps
-what was decided at capture time).  usage: tools/feature_ab.py <ctx attribute, e.g. gn_from_epilogue> [model] [rounds]"""
+what was decided at capture time).  usage: tools/feature_ab.py <ctx attribute, e.g. gn_from_epilogue | pipe.<attribute>> [model] [rounds]
+FIE_AB_FORK=1 keeps the two-stream graphs (needed for switches that move work between the streams; at most 6 captures = 3 rounds)."""
 import os
 import sys
 
@@ -16,15 +17,19 @@ rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 ed = FastEditor(model_name=model, use_full_controlnet=True, enable_cpu_offload=False)
 pipe = ed.pipe
 ctx = pipe.ctx
-assert isinstance(getattr(ctx, attr), bool), attr
-pipe.fork_streams = False      # single-stream graphs: immune to the hardware-queue collisions that many forked graphs in one process cause
+target = ctx
+if attr.startswith("pipe."):
+    target, attr = pipe, attr[5:]
+assert isinstance(getattr(target, attr), bool), attr
+if os.environ.get("FIE_AB_FORK", "0") != "1":
+    pipe.fork_streams = False      # single-stream graphs: immune to the hardware-queue collisions that many forked graphs in one process cause
 pipe.max_graphs = 64
 img = synth_item_image(3).resize((1024, 1024))
 ctrl = ed.preprocess_image(img)
 n_cap, outs = 0, {}
 for rnd in range(rounds):
     for on in (False, True):
-        setattr(ctx, attr, on)
+        setattr(target, attr, on)
         job = pipe.prepare("a photo of a [red] house", "", img, ctrl, 0.5, 4, 1.5 + 1e-4 * n_cap, 0.5, torch.Generator().manual_seed(42))
         n_cap += 1
         out = pipe.run_device_graphed(job)
