@@ -390,20 +390,32 @@ bool gn_onepass(fie_ctx* ctx, const GnArgsT<T>& p, int B) {
 constexpr int LN_MAXV = 8;   // 8 chunks x 8 values per lane
 
 // O8: the output is written as e4m3 bytes, value * inv8 saturated to +-448 (fie_layernorm_f16_o8: the consumer is an fp8-activation GEMM)
-template <typename T, bool O8 = false>
+// NV = 16-byte chunks per lane (2: C <= 1024, 3: C <= 1536, 8: the rest).  With NV <= 3 gamma / beta are loaded WITH the row, ahead of the two
+// reductions, instead of after them: the kernel is one latency chain (5-6 us for 5 MB), and the second round trip was a fifth of it.
+template <typename T, bool O8 = false, int NV = LN_MAXV>
 __global__ __launch_bounds__(256) void ln_kernel(const T* X, int64_t ldx, T* Y, int64_t ldy, int64_t rows,
                                                  int C, const T* gamma, const T* beta, float eps, float inv8 = 1.f) {
+    constexpr bool HOIST = NV <= 3;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nch = C >> 3;
-    float v[LN_MAXV][8];
+    float v[NV][8], g[HOIST ? NV : 1][8], bb[HOIST ? NV : 1][8];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
             fie_load8(X + row * ldx + ch * 8, v[i]);
+            if constexpr (HOIST) {
+                fie_load8(gamma + ch * 8, g[i]);
+                fie_load8(beta + ch * 8, bb[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (lane + 64 * i < nch) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) sum += v[i][j];
         }
@@ -413,7 +425,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* X, int64_t ldx, T* Y, 
     const float mean = sum / (float)C;
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
 #pragma unroll
@@ -427,14 +439,16 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* X, int64_t ldx, T* Y, 
     for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
     const float rstd = rsqrtf(var / (float)C + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
-            float g[8], bb[8], o[8];
-            fie_load8(gamma + ch * 8, g);
-            fie_load8(beta + ch * 8, bb);
+            float gl[8], bl[8], o[8];
+            if constexpr (!HOIST) {
+                fie_load8(gamma + ch * 8, gl);
+                fie_load8(beta + ch * 8, bl);
+            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
+            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * (HOIST ? g[HOIST ? i : 0][j] : gl[j]) + (HOIST ? bb[HOIST ? i : 0][j] : bl[j]);
             if constexpr (O8) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = fminf(fmaxf(o[j] * inv8, -448.f), 448.f);
@@ -448,6 +462,14 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* X, int64_t ldx, T* Y, 
             }
         }
     }
+}
+
+template <typename T, bool O8, typename... Args>
+void ln_launch(fie_ctx* ctx, int64_t rows, int C, Args... args) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (C <= 1024) fie_launch(ctx, (ln_kernel<T, O8, 2>), grid, block, 0, args...);
+    else if (C <= 1536) fie_launch(ctx, (ln_kernel<T, O8, 3>), grid, block, 0, args...);
+    else fie_launch(ctx, (ln_kernel<T, O8, LN_MAXV>), grid, block, 0, args...);
 }
 
 template <typename T>
@@ -509,7 +531,7 @@ int layernorm_t(const char* who, fie_ctx* ctx, const void* X, int64_t ldx, void*
     FIE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV, "%s: C=%d unsupported", who, C);
     FIE_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "%s: bad strides", who);
     FIE_DESC(ctx, "layernorm rows=%lld C=%d bytes=%.0f", (long long)rows, C, 2.0 * rows * C * sizeof(T));
-    fie_launch(ctx, (ln_kernel<T, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (const T*)X, ldx, (T*)Y, ldy, rows, C, (const T*)gamma, (const T*)beta, eps, 1.f);
+    ln_launch<T, false>(ctx, rows, C, (const T*)X, ldx, (T*)Y, ldy, rows, C, (const T*)gamma, (const T*)beta, eps, 1.f);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }
@@ -621,8 +643,7 @@ int fie_layernorm_f16_o8(fie_ctx* ctx, const void* X, int64_t ldx, void* Y8, int
     FIE_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXV && inv_scale > 0.f, "%s: C=%d unsupported", who, C);
     FIE_REQUIRE(ldx % 8 == 0 && ldy8 % 8 == 0 && ldx >= C && ldy8 >= C, "%s: bad strides", who);
     FIE_DESC(ctx, "layernorm->e4m3 rows=%lld C=%d bytes=%.0f", (long long)rows, C, 3.0 * rows * C);
-    fie_launch(ctx, (ln_kernel<half_t, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (const half_t*)X, ldx, (half_t*)Y8, ldy8, rows, C,
-               (const half_t*)gamma, (const half_t*)beta, eps, inv_scale);
+    ln_launch<half_t, true>(ctx, rows, C, (const half_t*)X, ldx, (half_t*)Y8, ldy8, rows, C, (const half_t*)gamma, (const half_t*)beta, eps, inv_scale);
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

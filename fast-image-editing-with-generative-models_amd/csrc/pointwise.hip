@@ -307,7 +307,45 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const unsigned* p, size_t
     asm volatile("" ::"v"(acc));
 }
 
+// out = a + b over n f16 values (n % 8 == 0): 16 B per lane and operand (the ControlNet residual adds of the C++ UNet walk, csrc/graphs.cpp;
+// the Python walk fuses them into the zero-conv epilogues instead)
+__global__ __launch_bounds__(256) void add_kernel(const half_t* a, const half_t* b, half_t* out, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float x[8], y[8];
+        fie_load8(a + i * 8, x);
+        fie_load8(b + i * 8, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += y[j];
+        fie_store8(out + i * 8, x);
+    }
+}
+
+// dst[r, 0..cols) = src[r, 0..cols) for `rows` rows (cols % 8 == 0; row strides in elements)
+__global__ __launch_bounds__(256) void copy_rows_kernel(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd, int rows, int cols8) {
+    const int64_t n = (int64_t)rows * cols8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / cols8), c = (int)(i - (int64_t)r * cols8);
+        *reinterpret_cast<uint4*>(dst + r * ldd + c * 8) = *reinterpret_cast<const uint4*>(src + r * lds_ + c * 8);
+    }
+}
+
 extern "C" {
+
+int fie_add_f16(fie_ctx* ctx, const void* a, const void* b, void* out, int64_t n) {
+    FIE_REQUIRE(ctx && a && b && out && n > 0 && n % 8 == 0, "fie_add_f16: bad argument");
+    const int64_t n8 = n / 8, blocks = (n8 + 255) / 256;
+    fie_launch(ctx, add_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (const half_t*)a, (const half_t*)b, (half_t*)out, n8);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+int fie_copy_rows_f16(fie_ctx* ctx, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols) {
+    FIE_REQUIRE(ctx && src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0, "fie_copy_rows_f16: bad argument");
+    const int64_t n = (int64_t)rows * (cols / 8), blocks = (n + 255) / 256;
+    fie_launch(ctx, copy_rows_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (const half_t*)src, ld_src, (half_t*)dst, ld_dst, rows, cols / 8);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
 
 int fie_prefetch(fie_ctx* ctx, const void* ptr, int64_t bytes, void* stream, int blocks) {
     FIE_REQUIRE(ctx && ptr && bytes > 0 && blocks > 0 && blocks <= 4096, "fie_prefetch: bad argument");

@@ -29,6 +29,17 @@ SIGNATURES = {
     "fie_weights_clear": [_P],
     "fie_vae_decode_workspace_bytes": [_P, _I, _I],
     "fie_vae_decode_f16": [_P, _P, _P, _P, _P, _L],
+    "fie_vae_encode_workspace_bytes": [_P],
+    "fie_vae_encode_f16": [_P, _P, _P, _P, _P, _L],
+    "fie_clip_text_workspace_bytes": [_P],
+    "fie_clip_text_forward_f16": [_P, _P, _c.c_char_p, _P, _P, _P, _P, _P, _L],
+    "fie_unet_num_residuals": [_P],
+    "fie_unet_workspace_bytes": [_P],
+    "fie_unet_forward_f16": [_P, _P, _c.c_char_p, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L],
+    "fie_controlnet_workspace_bytes": [_P],
+    "fie_controlnet_forward_f16": [_P, _P, _c.c_char_p, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _L],
+    "fie_add_f16": [_P, _P, _P, _P, _L],
+    "fie_copy_rows_f16": [_P, _P, _L, _P, _L, _I, _I],
     "fie_program_begin": [_P, _c.POINTER(_P)],
     "fie_program_end": [_P],
     "fie_program_launches": [_P],
@@ -129,7 +140,8 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.argtypes = args
-            fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes", "fie_time_embed_workspace_bytes", "fie_gn_stats_bytes", "fie_debug_oplog_read", "fie_vae_decode_workspace_bytes") else _I
+            fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes", "fie_time_embed_workspace_bytes", "fie_gn_stats_bytes", "fie_debug_oplog_read", "fie_vae_decode_workspace_bytes",
+                                       "fie_vae_encode_workspace_bytes", "fie_clip_text_workspace_bytes", "fie_unet_workspace_bytes", "fie_controlnet_workspace_bytes") else _I
         _lib.fie_last_error.restype = ctypes.c_char_p
         _lib.fie_last_error.argtypes = []
         _lib.fie_debug_last_gemm_kernel.restype = ctypes.c_char_p
@@ -162,6 +174,20 @@ class VaeConfig(ctypes.Structure):
     """include/fie.h: fie_vae_config (the C++ decoder walk, csrc/graphs.cpp)."""
     _fields_ = [("latent_h", _I), ("latent_w", _I), ("num_blocks", _I), ("block_out_channels", _I * 8), ("layers_per_block", _I),
                 ("norm_num_groups", _I), ("norm_eps", _F), ("out_channels", _I)]
+
+
+class ClipConfig(ctypes.Structure):
+    """include/fie.h: fie_clip_config."""
+    _fields_ = [("batch", _I), ("tokens", _I), ("hidden", _I), ("heads", _I), ("layers", _I), ("intermediate", _I), ("projection_dim", _I),
+                ("quick_gelu", _I), ("eps", _F)]
+
+
+class UnetConfig(ctypes.Structure):
+    """include/fie.h: fie_unet_config (UNet and ControlNet)."""
+    _fields_ = [("batch", _I), ("latent_h", _I), ("latent_w", _I), ("text_len", _I), ("num_blocks", _I), ("block_out_channels", _I * 4),
+                ("layers_per_block", _I), ("down_attn", (_I * 4) * 4), ("up_attn", (_I * 4) * 4), ("mid_attn", _I), ("mid_resnets", _I), ("head_dim", _I),
+                ("norm_num_groups", _I), ("norm_eps", _F), ("cross_attention_dim", _I), ("addition_time_embed_dim", _I), ("pooled_dim", _I),
+                ("num_cond_channels", _I), ("cond_channels", _I * 8)]
 
 
 class Program:

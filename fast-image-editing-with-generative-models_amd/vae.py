@@ -100,68 +100,3 @@ class VAE:
                 x = us(ctx, x, upsample=True, gn_groups=g)
         x = ctx.groupnorm(x, self.d_norm.g, self.d_norm.b, g, eps, True)
         return self.d_out(ctx, x)
-
-    # ------------------------------------------------------------------ the decoder as ONE C-ABI call (csrc/graphs.cpp)
-    def register_decoder(self):
-        """Hands the decoder's packed weights to the library by their diffusers names (include/fie.h: fie_weights_register); afterwards
-        `decode_cabi` runs the whole decoder through fie_vae_decode_f16, a graph walk written in C++ (what a non-Python host would call)."""
-        ctx = self.ctx
-        lib, h = hip.lib(), ctx.h
-        self._reg_keep = []
-
-        def reg(name, t, n, ld):
-            self._reg_keep.append(t)
-            hip._chk(lib.fie_weights_register(h, name.encode(), t.data_ptr(), int(n), int(ld)))
-
-        def conv(name, c):
-            assert torch.is_tensor(c.wp) and c.wp.dtype == torch.float16
-            reg(name + ".weight", c.wp, c.cout, c.wp.stride(0))
-            if c.b is not None:
-                reg(name + ".bias", c.b, c.b.numel(), 0)
-
-        def lin(name, l):
-            reg(name + ".weight", l.wp, l.n, l.wp.stride(0))
-            if l.b is not None:
-                reg(name + ".bias", l.b, l.b.numel(), 0)
-
-        def norm(name, nm):
-            reg(name + ".weight", nm.g, nm.g.numel(), 0)
-            reg(name + ".bias", nm.b, nm.b.numel(), 0)
-
-        def resnet(p, r):
-            norm(p + "norm1", r.n1); conv(p + "conv1", r.c1); norm(p + "norm2", r.n2); conv(p + "conv2", r.c2)
-            if r.sc is not None:
-                lin(p + "conv_shortcut", r.sc)
-
-        lin("post_quant_conv", self.post_quant)
-        conv("decoder.conv_in", self.d_in)
-        r0, at, r1 = self.d_mid
-        resnet("decoder.mid_block.resnets.0.", r0)
-        resnet("decoder.mid_block.resnets.1.", r1)
-        norm("decoder.mid_block.attentions.0.group_norm", at.norm)
-        lin("decoder.mid_block.attentions.0.to_qkv", at.qkv)
-        lin("decoder.mid_block.attentions.0.to_out.0", at.out)
-        for i, (rs, us) in enumerate(self.d_up):
-            for j, r in enumerate(rs):
-                resnet(f"decoder.up_blocks.{i}.resnets.{j}.", r)
-            if us is not None:
-                conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", us)
-        norm("decoder.conv_norm_out", self.d_norm)
-        conv("decoder.conv_out", self.d_out)
-
-    def decode_cabi(self, z):
-        """z: [1, h, w, 8] f16 -> [1, 8h, 8w, 4] f16 through fie_vae_decode_f16 (register_decoder() first)."""
-        import ctypes
-        ctx, cfg = self.ctx, self.cfg
-        ctx.sync_stream()
-        _, h, w, _ = z.shape
-        ch = cfg["block_out_channels"]
-        vc = hip.VaeConfig(h, w, len(ch), (ctypes.c_int * 8)(*ch), cfg["layers_per_block"], cfg["norm_num_groups"], cfg["norm_eps"], cfg["out_channels"])
-        need = hip.lib().fie_vae_decode_workspace_bytes(ctypes.byref(vc), h, w)
-        assert need > 0
-        ws = torch.empty(need, device=z.device, dtype=torch.uint8)
-        up = 2 ** (len(ch) - 1)
-        out = torch.zeros((1, h * up, w * up, 4), device=z.device, dtype=torch.float16)
-        hip._chk(hip.lib().fie_vae_decode_f16(ctx.h, ctypes.byref(vc), z.data_ptr(), out.data_ptr(), ws.data_ptr(), need))
-        return out
-

@@ -62,25 +62,26 @@ int fie_ctx_destroy(fie_ctx* ctx);
  * fie_program_run re-issues the whole list on the ctx stream from C++: no host-side shape logic, no Python, asynchronous and
  * hipGraph-capturable like any single op.  New inputs = new CONTENTS of the same input buffers.  The caller keeps every buffer
  * the program references alive and destroys programs it created.
- * What these entries are NOT: a C++ implementation of the model graphs.  The graph logic (which layer follows which, the shapes, the
- * weight packing) lives in the Python host code (fie_amd/nn.py, vae.py, clip.py); a named entry is a REPLAY HANDLE for a launch list that
- * walk recorded, with every pointer frozen in.  A non-Python host therefore cannot reach fie_unet_forward without first driving the op
- * entries below in graph order itself (fie_vae_decode_f16 above is the one graph that IS walked in C++; for the others the op entries take weight
- * pointers per call).  The product
- * path (hipGraph replay of the Python walk) does not go through these entries; tests/test_programs_gpu.py does.
+ * What the five NAMED entries (fie_unet_forward ...) are NOT: a C++ implementation of the model graphs.  They are REPLAY HANDLES for a launch list
+ * a host walk recorded, with every pointer frozen in.  The C++ implementations are the *_f16 forwards below (round 3).  The product path
+ * (hipGraph replay of the Python walk, which takes more fusions) goes through neither; tests/test_programs_gpu.py covers both.
  *   fie_graph_register binds a program to one of the names "unet_forward", "controlnet_forward", "vae_encode", "vae_decode",
  *   "clip_text_forward"; the five named entries run the program bound to their name (FIE_EINVAL if none). */
-/* ---- A graph-level forward that IS a forward (round 3): the AutoencoderKL decoder (upstream models/autoencoders/vae.py Decoder behind
- * AutoencoderKL.decode, the last model call of the pipeline call at /root/reference/src/pipeline.py:261-272) sequenced in C++ over the op entries
- * below (csrc/graphs.cpp), on weights registered once by their diffusers parameter names -- tensor arguments in and out, no Python graph code, no
- * recorded launch list.
- *   fie_weights_register(name, ptr, n, ld): "<conv>.weight" = fie_pack_conv3x3_f16 output (n = Cout, ld = ldw), "<linear>.weight" =
- *     fie_pack_rows_f16 output, biases / norm gains as plain f16 vectors (ld = 0); the mid-block attention's q | k | v as ONE packed matrix
- *     "decoder.mid_block.attentions.0.to_qkv.{weight,bias}"; "post_quant_conv.{weight,bias}" zero-padded to the 8-channel latent layout.
- *   fie_vae_decode_f16: z = [1, latent_h, latent_w, 8] f16 (latents / scaling_factor, 4 real channels) -> out = [1, 8 h, 8 w, 4] f16 (3 real
- *     channels); workspace >= fie_vae_decode_workspace_bytes (five rotating activation buffers + GroupNorm scratch).  Asynchronous on the ctx
- *     stream, hipGraph-capturable.  Same kernels and order as the Python walk (fie_amd/vae.py) apart from two fusions it does not take (GroupNorm
- *     sums from the producing epilogue, 2x2-parity up-samplers): results agree to rounding. */
+/* ---- Graph-level forwards that ARE forwards (round 3, csrc/graphs.cpp): the five model calls inside the pipeline call at
+ * /root/reference/src/pipeline.py:261-272 sequenced in C++ over the op entries below, on weights registered once by name -- tensor arguments in
+ * and out, no Python graph code, no recorded launch list; what a non-Python host binds.
+ *   fie_weights_register(name, ptr, n, ld): name = "<prefix><diffusers parameter name>" (prefix = the `prefix` argument of the forward, "" for the
+ *     VAE).  "<conv>.weight" = fie_pack_conv3x3_f16 output (n = Cout, ld = ldw), "<linear>.weight" = fie_pack_rows_f16 output (n = N), biases /
+ *     norm gains as plain f16 vectors (ld = 0).  Fused matrices (rows concatenated, then packed; biases likewise): "...attn1.to_qkv",
+ *     "...attn2.to_kv", "...self_attn.qkv_proj" (CLIP), "<vae>.mid_block.attentions.0.to_qkv", "time_emb_proj_all" (every resnet's time_emb_proj
+ *     in walk order: down, mid, up); "...ff.net.0.proj" in the GEGLU layout (fie_pack_rows_f16 with geglu: value / gate rows interleaved, bias
+ *     likewise); "post_quant_conv.{weight,bias}" zero-padded to the 8-channel latent layout; CLIP: "zero_row" = `hidden` zeros.
+ *   Workspaces: ONE caller-provided device buffer per call, >= the matching *_workspace_bytes(cfg) (the walk's allocation sequence replayed
+ *     without launching: exact).  Asynchronous on the ctx stream, hipGraph-capturable, no allocation, no synchronisation.
+ *   Same kernels and order as the Python walks (fie_amd/{clip,vae,nn}.py) apart from fusions those take and these do not (GroupNorm sums from the
+ *     producing epilogue, 2x2-parity up-samplers, conv2 + shortcut as one GEMM, the one-launch timestep embedding, zero convs adding into the UNet's
+ *     skips): results agree to rounding (tests/test_programs_gpu.py: <= 3e-3 of the output's max against the Python walk at full size).
+ *   Layouts: activations NHWC f16; images and latents 8-channel zero-padded ([B, H, W, 8]); eps / VAE pixels 4-channel ([.., 4], 3 or 4 real). */
 typedef struct fie_vae_config {
     int latent_h, latent_w;
     int num_blocks;                /* len(block_out_channels), <= 8 */
@@ -90,10 +91,63 @@ typedef struct fie_vae_config {
     float norm_eps;                /* 1e-6 */
     int out_channels;              /* 3 */
 } fie_vae_config;
+typedef struct fie_clip_config {
+    int batch, tokens;             /* ids: int32 [batch * tokens] on the device */
+    int hidden, heads, layers, intermediate;
+    int projection_dim;            /* 0: no text_projection (CLIP-L as SDXL uses it): the last layer is not run */
+    int quick_gelu;                /* 1: quick_gelu (CLIP-L), 0: gelu (OpenCLIP bigG) */
+    float eps;                     /* 1e-5 */
+} fie_clip_config;
+typedef struct fie_unet_config {   /* UNet2DConditionModel (SDXL family) and the ControlNetModel built on its encoder */
+    int batch;                     /* rows of x (CFG rows included) */
+    int latent_h, latent_w;        /* multiples of 2^(num_blocks - 1) */
+    int text_len;                  /* text rows per batch row (77) */
+    int num_blocks;                /* <= 4 */
+    int block_out_channels[4];     /* 320, 640, 1280 */
+    int layers_per_block;          /* 2 (<= 3) */
+    int down_attn[4][4];           /* transformer depth behind resnet j of down block i (0: none) */
+    int up_attn[4][4];             /* likewise for the layers_per_block + 1 resnets of up block i (UNet only) */
+    int mid_attn;                  /* depth of the mid-block transformer (0: none) */
+    int mid_resnets;               /* 2: resnet, transformer, resnet;  1: one resnet */
+    int head_dim;                  /* 64 */
+    int norm_num_groups;           /* 32 */
+    float norm_eps;                /* 1e-5 */
+    int cross_attention_dim;       /* 2048 */
+    int addition_time_embed_dim;   /* 256 */
+    int pooled_dim;                /* 1280: add_embedding.linear_1 reads pooled_dim + 6 * addition_time_embed_dim columns */
+    int num_cond_channels;         /* ControlNet only: len(conditioning_embedding_out_channels), <= 8; cond is [B, h * 2^(n-1), w * 2^(n-1), 8] */
+    int cond_channels[8];          /* 16, 32, 96, 256 */
+} fie_unet_config;
 int fie_weights_register(fie_ctx* ctx, const char* name, const void* ptr, int64_t n, int64_t ld);
 int fie_weights_clear(fie_ctx* ctx);
+/* AutoencoderKL.decode(latents / scaling_factor): z [1, h, w, 8] -> out [1, 8 h, 8 w, 4];  names "post_quant_conv", "decoder...." */
 int64_t fie_vae_decode_workspace_bytes(const fie_vae_config* cfg, int latent_h, int latent_w);
 int fie_vae_decode_f16(fie_ctx* ctx, const fie_vae_config* cfg, const void* z, void* out, void* workspace, int64_t workspace_bytes);
+/* AutoencoderKL.encode(x).latent_dist parameters: x [1, 8 h, 8 w, 8] in [-1, 1] -> moments [h * w, 8] (mean | logvar);  names "encoder....", "quant_conv" */
+int64_t fie_vae_encode_workspace_bytes(const fie_vae_config* cfg);
+int fie_vae_encode_f16(fie_ctx* ctx, const fie_vae_config* cfg, const void* x, void* moments, void* workspace, int64_t workspace_bytes);
+/* CLIPTextModel(.WithProjection)(ids, output_hidden_states=True): penultimate = hidden_states[-2] [batch * tokens, hidden]; pooled (projection_dim > 0
+ * and pooled != NULL) = text_projection(final_layer_norm(last)[eos_rows]) [batch, projection_dim]; eos_rows: int32 [batch] ROW indices b * tokens + eos */
+int64_t fie_clip_text_workspace_bytes(const fie_clip_config* cfg);
+int fie_clip_text_forward_f16(fie_ctx* ctx, const fie_clip_config* cfg, const char* prefix, const int32_t* ids, const int32_t* eos_rows, void* penultimate,
+                              void* pooled, void* workspace, int64_t workspace_bytes);
+/* UNet2DConditionModel.forward(sample, t, encoder_hidden_states, added_cond_kwargs = {text_embeds, time_ids}, down_block_additional_residuals,
+ * mid_block_additional_residual): x [B, h, w, 8], t f32 [B], text [B * text_len, cross_attention_dim], pooled [B, pooled_dim], time_ids f32 [B, 6]
+ * (all on the device) -> eps [B, h, w, 4].  down_residuals: fie_unet_num_residuals(cfg) device pointers in skip order (conv_in output first), or NULL. */
+int fie_unet_num_residuals(const fie_unet_config* cfg);
+int64_t fie_unet_workspace_bytes(const fie_unet_config* cfg);
+int fie_unet_forward_f16(fie_ctx* ctx, const fie_unet_config* cfg, const char* prefix, const void* x, const float* t, const void* text, const void* pooled,
+                         const float* time_ids, const void* const* down_residuals, const void* mid_residual, void* eps_out, void* workspace,
+                         int64_t workspace_bytes);
+/* ControlNetModel.forward(sample, t, encoder_hidden_states, controlnet_cond, conditioning_scale, added_cond_kwargs): cond [B, H, W, 8] in [0, 1] ->
+ * down_out[i] (shapes of the UNet's skips), mid_out: the zero-conv outputs times conditioning_scale, as upstream returns them */
+int64_t fie_controlnet_workspace_bytes(const fie_unet_config* cfg);
+int fie_controlnet_forward_f16(fie_ctx* ctx, const fie_unet_config* cfg, const char* prefix, const void* x, const float* t, const void* text, const void* pooled,
+                               const float* time_ids, const void* cond, float conditioning_scale, void* const* down_out, void* mid_out, void* workspace,
+                               int64_t workspace_bytes);
+/* the two element-wise helpers the walks need (also plain ops): out = a + b over n f16 values (n % 8 == 0); a strided row copy (cols % 8 == 0) */
+int fie_add_f16(fie_ctx* ctx, const void* a, const void* b, void* out, int64_t n);
+int fie_copy_rows_f16(fie_ctx* ctx, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols);
 
 typedef struct fie_program fie_program;
 int fie_program_begin(fie_ctx* ctx, fie_program** out);

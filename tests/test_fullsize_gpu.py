@@ -282,3 +282,28 @@ def test_full_size_edit_fp32_vs_oracle(full, oracle_edit, fie):
                          generator=torch.Generator("cpu").manual_seed(42), **_EDIT_KW).images[0])
     dmax = _compare("fp32 HIP edit", out, ref)
     assert dmax <= 4
+
+
+def test_full_size_edit_through_the_c_abi_forwards(full, oracle_edit):
+    """The same edit with EVERY model call going through a graph-level C-ABI forward (fie_clip_text_forward_f16 x 2, fie_vae_encode_f16, 2 x
+    (fie_controlnet_forward_f16 + fie_unet_forward_f16), fie_vae_decode_f16: csrc/graphs.cpp walks in C++ on registered weights; fie_amd/cabi.py
+    only passes pointers) -- the call sequence of a non-Python host: against the oracle's edit (SSIM >= 0.99) and against the product path."""
+    import time
+    from fie_amd import cabi
+    cfgs, sds32, pipe = full
+    img, ctrl, ref = oracle_edit
+    cabi.register_pipeline(pipe)
+    job = pipe.prepare(_PROMPT, "", img, ctrl, generator=torch.Generator("cpu").manual_seed(42), **_EDIT_KW)
+    out = cabi.run_edit(pipe, job)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out = cabi.run_edit(pipe, job)
+    torch.cuda.synchronize()
+    print(f"edit through the C-ABI forwards (eager, one stream): {(time.time() - t0) * 1e3:.1f} ms")
+    out = out.cpu().numpy()
+    _compare("edit through the C-ABI forwards", out, ref)
+    pipe.use_graph = False
+    prod = np.asarray(pipe(prompt=_PROMPT, negative_prompt="", image=img, control_image=ctrl, generator=torch.Generator("cpu").manual_seed(42), **_EDIT_KW).images[0])
+    d = np.abs(out.astype(int) - prod.astype(int))
+    print(f"C-ABI forwards vs the product path: max|du8|={d.max()} mean|du8|={d.mean():.4f}")
+    assert d.max() <= 3

@@ -132,50 +132,3 @@ def test_program_inside_a_hipgraph(rig, fie):
     torch.cuda.synchronize()
     assert torch.equal(dec, ref)
     pd.close()
-
-
-@pytest.mark.parametrize("stack_name,lat", [("tiny", 16), ("ssd-1b", 128)])
-def test_vae_decode_walked_in_cpp(fie, stack_name, lat):
-    """fie_vae_decode_f16 (csrc/graphs.cpp): the AutoencoderKL decoder sequenced in C++ over the op entries on weights registered by their
-    diffusers names -- tensor arguments, no Python graph code, no recorded launch list.  Against the Python walk (fie_amd/vae.py::VAE.decode,
-    which also takes the GroupNorm-sums-from-the-epilogue and 2x2-parity up-sampler fusions the C++ walk leaves out: agreement to rounding) and,
-    on the tiny stack, against the CPU oracle; replay inside a hipGraph; a missing weight is an error, not a crash."""
-    import ctypes
-    from fie_amd import hip, stack, weights
-    from fie_amd.vae import VAE
-    cfgs = stack.stack_configs(stack_name, True)
-    sd = weights.synth_state_dict(cfgs["vae"], seed=1236, device="cpu", dtype=torch.float16)
-    vae = VAE(fie, cfgs["vae"], sd)
-    g = torch.Generator().manual_seed(4)
-    z = torch.zeros(1, lat, lat, 8, dtype=torch.float16)
-    z[..., :4] = torch.randn(1, lat, lat, 4, generator=g).half()
-    zd = z.to(fie.device)
-    ref = vae.decode(zd).float()
-    vae.register_decoder()
-    out = vae.decode_cabi(zd)
-    assert out.shape == ref.shape
-    err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
-    print(f"C++ decoder walk vs Python walk ({stack_name}, {lat}x{lat} latents): rel. max-abs error {err:.2e}")
-    assert err < 4e-3 and out[..., 3].abs().max() == 0
-    if stack_name == "tiny":
-        from oracle import nets
-        with torch.no_grad():
-            oref = nets.vae_decode({k: v.float() for k, v in sd.items()}, cfgs["vae"], z[..., :4].permute(0, 3, 1, 2).float())
-        assert ((out[0, ..., :3].permute(2, 0, 1).float().cpu() - oref[0]).abs().max() / oref.abs().max()).item() < 2e-2
-        # capturable: the whole C++ walk inside a hipGraph, replayed on new latents
-        s = torch.cuda.Stream()
-        with torch.cuda.stream(s):
-            static_z = zd.clone()
-            vae.decode_cabi(static_z)
-            torch.cuda.synchronize()
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, stream=s):
-                cap = vae.decode_cabi(static_z)
-            static_z.copy_(zd * 0.5)
-            gr.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(cap, vae.decode_cabi(zd * 0.5))
-        # a weight that was never registered: FIE_EINVAL with its name, nothing launched past it
-        hip._chk(hip.lib().fie_weights_clear(fie.h))
-        with pytest.raises(hip.FieError, match="post_quant_conv.weight"):
-            vae.decode_cabi(zd)
