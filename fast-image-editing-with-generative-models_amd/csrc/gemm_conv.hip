@@ -171,18 +171,20 @@ __device__ __forceinline__ void read_frags(f16x8 (&f)[N], unsigned addr, std::in
 // front of them, is 15-30 % slower on every hot-path GEMM -- profiles/r03_interleaved_dma_issue_negative.log -- and was removed again.)
 template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0
 __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
-    constexpr int WGN = NW / 2;
-    constexpr int WM = BM / 2, WN = BN / WGN;
+    // waves as 2 (rows) x NW/2 (columns) wherever that leaves whole 16-column fragments; otherwise (128x80) all NW waves stacked along the rows
+    constexpr int WGN = (BN / (NW / 2)) % 16 == 0 ? NW / 2 : 1, WGM = NW / WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int FM = WM / 16, FN = WN / 16;
-    constexpr int RA = BM / (8 * NW), RW = BN / (8 * NW);
-    constexpr int NP = RA + RW;
+    constexpr int NPW = BN / 8;                            // weight pieces (8 rows x 128 B) per K-step
+    constexpr int RA = BM / (8 * NW), RW = (NPW + NW - 1) / NW;
+    constexpr int NP = RA + RW;                            // EVERY wave issues NP pieces per K-step (the counted waits rely on it): see issue_w for ragged NPW
     constexpr int STAGE = (BM + BN) * BK;
     extern __shared__ __attribute__((aligned(16))) half_t smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WGM, wn = wave / WGM;
 
     // split-K: consecutive (remapped) block ids = the slices of one tile, so they share an XCD's L2 for the tile's operands and slabs
     const int bid_all = xcd_remap(blockIdx.x, gridDim.x);
@@ -292,7 +294,11 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         half_t* sw = smem + stage * STAGE + BM * BK;
         const unsigned sow = (unsigned)kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < RW; ++i) bload16(rs_w, sw + (wave + NW * i) * 512, w_base + (unsigned)i * w_step, sow);
+        for (int i = 0; i < RW; ++i) {
+            // ragged piece count (128x80: 10 pieces over 4 waves): a wave without an i-th piece re-issues its first one (same data, same place)
+            const int ii = (NPW % NW == 0 || wave + NW * i < NPW) ? i : 0;
+            bload16(rs_w, sw + (wave + NW * ii) * 512, w_base + (unsigned)ii * w_step, sow);
+        }
     };
 
     f32x4 acc[FN][FM];
@@ -482,6 +488,7 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
 //   52 / 54        gemm3_kernel  128x128 / 192x128, 2 stages, 8 waves: two blocks per CU
 //   47             gemm3_kernel  128x96, 3 stages, 4 waves: 224 tiles for M 2048 x N 1280 (one per CU, each streaming a 96-row weight tile:
 //                  the 32x32-latent convs lose nothing on cold weights with it, 7-9 % with 128x128)
+//   48             gemm3_kernel  128x80, 3 stages, 4 waves stacked along the rows (wave tile 32x80); M 2048 x N 1280 = 256 tiles, one per CU
 //   51             gemm3_kernel  128x128, 3 stages, 8 waves
 //   61 / 62        gemm3_kernel  256x256 x 2 stages / 256x128 x 3 stages, 8 waves
 //   63             gemm3_kernel  256x320 x 2 stages, 8 waves (wave tile 128x80): exactly ONE tile per CU for the FF1 projection M 2048 x N 10240
@@ -494,7 +501,7 @@ struct TileDim { int code, bm, bn; };
 constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {42, 128, 64}, {43, 64, 64},
                               {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256},
                               {63, 256, 320}, {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
-                              {52, 128, 128}, {47, 128, 96}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}};
+                              {52, 128, 128}, {47, 128, 96}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}, {48, 128, 80}};
 
 // Heuristic tile code for a shape (the default; the autotuner below and the debug hooks can replace it).
 template <int MODE>
@@ -628,6 +635,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
             break;
         case 52: launch_ring<128, 128, 2, M3, 8>(ctx, a, grid); break;
         case 47: launch_ring<128, 96, 3, M3, 4>(ctx, a, grid); break;
+        case 48: launch_ring<128, 80, 3, M3, 4>(ctx, a, grid); break;       // weight rows past the packed matrix (80 does not divide Npad) read as zero through the descriptor
         case 54: launch_ring<192, 128, 2, M3, 8>(ctx, a, grid); break;
         case 46: launch_ring<64, 64, 2, M3, 4>(ctx, a, grid); break;
         case 44: launch_ring<128, 64, 2, M3, 4>(ctx, a, grid); break;
@@ -657,7 +665,7 @@ constexpr size_t kFlushBytes = 384u << 20;
 
 template <int MODE>
 int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
-    static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81, 63, 47};      // 47 (128x96): FIE_TUNE_47=0 leaves it out
+    static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81, 63, 47, 48};      // 47 (128x96): FIE_TUNE_47=0 leaves it out
     static const bool use47 = !(getenv("FIE_TUNE_47") && getenv("FIE_TUNE_47")[0] == '0');
     static const int kW8[] = {43, 42, 62, 52, 54};
     static const int kX8[] = {43, 42, 47, 51, 52, 54, 62, 63};
@@ -698,7 +706,7 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     float t_best = t_guess * 0.97f;                          // a challenger has to win by 3 %
     const bool x8 = a.w_scale && a.a_scale != 0.f;
     const int* cand = x8 ? kX8 : a.w_scale ? kW8 : kRing;
-    const int ncand = x8 ? 8 : a.w_scale ? 5 : use47 ? 11 : 10;
+    const int ncand = x8 ? 8 : a.w_scale ? 5 : 12;
     auto excluded = [&](int c) {
         for (int e : ctx->tune_exclude)
             if (e == c) return e != 0;
@@ -710,6 +718,8 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
         if ((c == 43 || c == 46) && blocks(64, 64) > 64 * ctx->num_cus) continue;       // tens of thousands of tiny tiles: never wins
         if ((c == 81 || c == 96 || c == 62) && 2 * blocks(256, 128) < ctx->num_cus) continue;
         if (c == 63 && (MODE != 0 || a.N % 320 != 0 || 2 * blocks(256, 320) < ctx->num_cus)) continue;
+        if (c == 47 && !use47) continue;
+        if (c == 48 && (a.N % 80 != 0 || blocks(128, 80) > 2 * ctx->num_cus)) continue;      // the exact-fit tile of the N = 1280 projections: small grids only
         if (x8 && MODE == 1 && c == 63) continue;
         if (x8 && (c == 62 || c == 51) && 2 * blocks(c == 62 ? 256 : 128, 128) < ctx->num_cus) continue;
         if (c == 81 && MODE == 1 && a.A2) continue;            // side inputs: ring kernels only
@@ -825,6 +835,7 @@ hipError_t ring_attrs() {
     if (e == hipSuccess && MODE == 0) e = ring_attr<256, 320, 2, 0, 8>();
     if (e == hipSuccess) e = ring_attr<128, 128, 2, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<128, 96, 3, MODE, 4>();
+    if (e == hipSuccess) e = ring_attr<128, 80, 3, MODE, 4>();
     if (e == hipSuccess) e = ring_attr<192, 128, 2, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<64, 64, 2, MODE, 4>();
     if (e == hipSuccess) e = ring_attr<128, 64, 2, MODE, 4>();

@@ -260,7 +260,7 @@ def test_clip_embed(fie):
     assert rel_err(out, ref) < 2e-3
 
 
-@pytest.mark.parametrize("code", [1, 2, 3, 42, 43, 44, 46, 47, 51, 52, 54, 61, 62, 81, 82, 95, 96, 1042, 2042, 1062, 2081,
+@pytest.mark.parametrize("code", [1, 2, 3, 42, 43, 44, 46, 47, 48, 20048, 51, 52, 54, 61, 62, 81, 82, 95, 96, 1042, 2042, 1062, 2081,
                                   20096, 30096, 40096, 30095, 20051, 30047, 20054, 40052, 30042, 20043, 21096, 32047])
 def test_gemm_conv_every_shipped_kernel(fie, code):
     """Every kernel / tile the launch table can select (gemm_conv.hip kTiles; + 2000 = m-tiles-fastest order; + 10000 * s =
@@ -338,7 +338,7 @@ def test_gemm_view_only_tiles(fie, code):
         fie.force_tile(0)
 
 
-@pytest.mark.parametrize("code", [42, 43, 44, 47, 51, 52, 54, 62, 95, 96])
+@pytest.mark.parametrize("code", [42, 43, 44, 47, 48, 51, 52, 54, 62, 95, 96])
 def test_epilogue_operands_loaded_ahead_of_the_k_loop(fie, code):
     """Ring kernels read the bias row and the residual tile BEFORE the K loop (gemm_common.h: EpiPre; round 3).  Same values, same
     arithmetic: bit-identical to the in-epilogue loads (fie_debug_epilogue_prefetch 0), ragged edges and an in-place residual included,

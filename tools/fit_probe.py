@@ -14,7 +14,7 @@ from tools.cold_weights import time_rot  # noqa: E402
 
 ctx = hip.context(0)
 for k in (1280, 5120):
-    for code, ns in ((42, (1024, 1280)), (47, (1280,)), (43, (1280,)), (96, (1280, 3840)), (52, (1280,))):
+    for code, ns in ((42, (1280,)), (47, (1280,)), (48, (1280,))):
         for n in ns:
             m = 2048
             copies = max(2, int(600e6 / (n * k * 2)) + 1)
@@ -31,7 +31,7 @@ for k in (1280, 5120):
                 print(code, n, "n/a", e)
                 continue
             cells = []
-            for pre in (False, True, False, True):
+            for pre in (True, True):
                 ctx.epi_prefetch = pre
                 cold = statistics.median(time_rot(fns, max(40, len(fns))) for _ in range(5))
                 cells.append(f"{'pre' if pre else 'epi'} {cold * 1e6:6.1f} us")
