@@ -225,10 +225,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgsT<T> p) {
     }
     const int64_t r_begin = (int64_t)blockIdx.x * p.rows_per_chunk;
     const int64_t r_end = min(r_begin + p.rows_per_chunk, p.rows);
-    for (int64_t r = r_begin + rsub; r < r_end; r += p.rpp) {
-        const int64_t rg = (int64_t)b * p.rows + r;
-        float v[8], o[8];
-        gn_load(p, rg, c0, v);
+    auto emit = [&](int64_t rg, const float (&v)[8]) {
+        float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float y = v[j] * sc[j] + sh[j];
@@ -239,6 +237,21 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GnArgsT<T> p) {
             *reinterpret_cast<int2*>(reinterpret_cast<unsigned char*>(p.Y) + rg * p.C + c0) = make_int2(gn_pack4_f8(o, p.o8_inv), gn_pack4_f8(o + 4, p.o8_inv));
         else
             fie_store8(p.Y + rg * p.C + c0, o);
+    };
+    // four rows in flight per thread: with one, a fully occupied chip holds ~8 MB of loads = ~4 TB/s at HBM latency (measured 4.4-5.3 on the VAE maps)
+    constexpr int U = 4;
+    int64_t r = r_begin + rsub;
+    for (; r + (int64_t)(U - 1) * p.rpp < r_end; r += (int64_t)U * p.rpp) {
+        float v[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) gn_load(p, (int64_t)b * p.rows + r + (int64_t)u * p.rpp, c0, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) emit((int64_t)b * p.rows + r + (int64_t)u * p.rpp, v[u]);
+    }
+    for (; r < r_end; r += p.rpp) {
+        float v[8];
+        gn_load(p, (int64_t)b * p.rows + r, c0, v);
+        emit((int64_t)b * p.rows + r, v);
     }
 }
 
