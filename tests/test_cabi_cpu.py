@@ -168,3 +168,34 @@ def test_lanczos_tables_match_pillow(h, w, oh, ow):
     a[: h // 2] = (np.linspace(0, 255, w)[None, :, None] * np.ones((h // 2, 1, 3))).astype(np.uint8)      # smooth half + noise half
     ref = np.asarray(Image.fromarray(a).resize((ow, oh), Image.LANCZOS))
     assert np.array_equal(resize.resample_numpy(a, oh, ow), ref)
+
+
+def test_graph_walk_workspace_queries_run_on_the_host(lib):
+    """fie_*_workspace_bytes (csrc/graphs.cpp) replay the C++ walks' allocation sequence WITHOUT launching: pure host code, so the CPU suite can
+    check the walks' bookkeeping -- sane sizes at the BASELINE configuration, monotone in batch and resolution, -1 for configs the walks refuse."""
+    import ctypes
+    from fie_amd import cabi, stack
+    cfgs = stack.stack_configs("ssd-1b", True)
+    uc = cabi.unet_config(cfgs["unet"], 2, 128, 128, 77)
+    unet = lib.fie_unet_workspace_bytes(ctypes.byref(uc))
+    cc = cabi.unet_config(cfgs["controlnet"], 2, 128, 128, 77)
+    cn = lib.fie_controlnet_workspace_bytes(ctypes.byref(cc))
+    assert 100e6 < unet < 2e9 and 100e6 < cn < 2e9, (unet, cn)
+    assert lib.fie_unet_num_residuals(ctypes.byref(uc)) == len(cabi.skip_shapes(cfgs["unet"], 2, 128, 128)[0]) == 9
+    uc1 = cabi.unet_config(cfgs["unet"], 1, 128, 128, 77)
+    uc64 = cabi.unet_config(cfgs["unet"], 2, 64, 64, 77)
+    assert lib.fie_unet_workspace_bytes(ctypes.byref(uc1)) < unet and lib.fie_unet_workspace_bytes(ctypes.byref(uc64)) < unet
+    uc.latent_h = 126                                        # not a multiple of 2^(blocks - 1)
+    assert lib.fie_unet_workspace_bytes(ctypes.byref(uc)) == -1
+    cc.num_cond_channels = 0
+    assert lib.fie_controlnet_workspace_bytes(ctypes.byref(cc)) == -1
+    vc = cabi.vae_config(cfgs["vae"], 128, 128)
+    dec, enc = lib.fie_vae_decode_workspace_bytes(ctypes.byref(vc), 128, 128), lib.fie_vae_encode_workspace_bytes(ctypes.byref(vc))
+    assert 0.5e9 < dec < 4e9 and 0.5e9 < enc < 4e9, (dec, enc)           # three or four live 1024x1024x128 f16 maps (268 MB each) + GroupNorm scratch
+    vc.num_blocks = 0
+    assert lib.fie_vae_encode_workspace_bytes(ctypes.byref(vc)) == -1
+    for key in ("clip_l", "clip_g"):
+        c = cfgs[key]
+        k = hip.ClipConfig(2, 77, c["hidden"], c["heads"], c["layers"], c["intermediate"], c["projection_dim"] or 0, 1 if c["act"] == "quick_gelu" else 0, c["eps"])
+        need = lib.fie_clip_text_workspace_bytes(ctypes.byref(k))
+        assert 154 * c["hidden"] * 2 * 3 < need < 154 * c["intermediate"] * 2 * 8, (key, need)
