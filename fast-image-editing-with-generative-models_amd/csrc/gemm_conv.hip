@@ -169,8 +169,13 @@ __device__ __forceinline__ void read_frags(f16x8 (&f)[N], unsigned addr, std::in
 
 // (Round 3 negative result: issuing the K-step's DMA pieces one at a time BETWEEN the MFMAs of the 4-wave tiles, instead of as one burst in
 // front of them, is 15-30 % slower on every hot-path GEMM -- profiles/r03_interleaved_dma_issue_negative.log -- and was removed again.)
-template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0
+// ALT (8-wave tiles, GEMM view): the two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) take TURNS issuing a K-step's whole LDS-DMA refill.
+// A K-step of these kernels is a serial sum -- DMA issue (the waves sit in the 64 B/clk load path) + fragment reads + MFMAs + barrier -- because every
+// wave does the same thing at the same time; with turns, the group that issues nothing goes straight to its reads and MFMAs while the other one feeds the
+// load path, and in the next K-step they swap.
+template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false, bool ALT = false>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0
 __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
+    static_assert(!ALT || (NW == 8 && MODE == 0 && !PF && !STAMP), "ALT: 8-wave GEMM-view tiles without the fragment prefetch");
     // waves as 2 (rows) x NW/2 (columns) wherever that leaves whole 16-column fragments; otherwise (128x80) all NW waves stacked along the rows
     constexpr int WGN = (BN / (NW / 2)) % 16 == 0 ? NW / 2 : 1, WGM = NW / WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -301,6 +306,32 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         }
     };
 
+    // ALT: this wave's share when its group refills a whole stage alone: pieces lw + 4 i of the 2 RA activation and 2 RW weight pieces
+    const int grp = wave >> 2, lw = wave & 3;
+    const unsigned alt_a1 = (unsigned)(lm0 + lw * 8 + lr) * (unsigned)p.lda1 * 2u + c8 * 16u, alt_a2 = (unsigned)(lm0 + lw * 8 + lr) * (unsigned)p.lda2 * 2u + c8 * 16u;
+    const unsigned alt_sa1 = 32u * (unsigned)p.lda1 * 2u, alt_sa2 = 32u * (unsigned)p.lda2 * 2u;
+    const unsigned alt_w = (unsigned)(ln0 + lw * 8 + lr) * (unsigned)p.ldw * 2u + c8 * 16u, alt_sw = 32u * (unsigned)p.ldw * 2u;
+    auto issue_alt = [&](int kt, int stage) {
+        half_t* sa = smem + stage * STAGE;
+        half_t* sw = sa + BM * BK;
+        if (ktail && kt == nk_all - 1) {
+            const bool in_k = kt * BK + c8 * 8 < p.K;
+#pragma unroll
+            for (int i = 0; i < 2 * RA; ++i) bload16(rs_a1, sa + (lw + 4 * i) * 512, in_k ? alt_a1 + (unsigned)i * alt_sa1 : kOob, (unsigned)kt * (BK * 2));
+        } else if (kt < k1_steps || k1_steps == 0) {
+            const unsigned so = (unsigned)kt * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < 2 * RA; ++i) bload16(rs_a1, sa + (lw + 4 * i) * 512, alt_a1 + (unsigned)i * alt_sa1, so);
+        } else {
+            const unsigned so = (unsigned)(kt - k1_steps) * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < 2 * RA; ++i) bload16(rs_a2, sa + (lw + 4 * i) * 512, alt_a2 + (unsigned)i * alt_sa2, so);
+        }
+        const unsigned sow = (unsigned)kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 2 * RW; ++i) bload16(rs_w, sw + (lw + 4 * i) * 512, alt_w + (unsigned)i * alt_sw, sow);
+    };
+
     f32x4 acc[FN][FM];
 #pragma unroll
     for (int i = 0; i < FN; ++i)
@@ -397,6 +428,12 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     } else
     for (int kt = 0; kt < nk; ++kt) {
         const int later = min(kt + ST - 2, nk - 1) - kt;
+        if constexpr (ALT && ST >= 3) {
+            // stage kt was issued (whole) by group kt & 1 two K-steps ago, stage kt + 1 by the other group one K-step ago: the group that owns
+            // stage kt drains, the other one may keep its 2 NP pieces of stage kt + 1 in flight (the prologue is issued by all waves: kt < ST - 1 drains)
+            if (later >= 1 && kt >= ST - 1 && (kt & 1) != grp) wait_vm_barrier<2 * NP>();
+            else wait_vm_barrier<0>();
+        } else
         wait_stage<NP, ST>(later);
         stamp(kt == 0 ? 7 : 0);                            // 0: MFMA drain + barrier wait
         const bool more = kt + ST - 1 < nk;
@@ -407,8 +444,12 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             // spends a whole K-step's worth of LDS-DMA issue slots before its first MFMA
             // (measured: pays for the 8-wave blocks, costs 10 % on the 4-wave ones, which keep one burst per K-step)
             if (more && p.probe != 3) {                // probe 3: no DMA issued inside the K loop at all (stale LDS data)
-                if (kk == 0) { issue(kbeg + kt + ST - 1, fill); if (NW != 8) issue_w(kbeg + kt + ST - 1, fill); }
-                else if (NW == 8) issue_w(kbeg + kt + ST - 1, fill);
+                if constexpr (ALT) {
+                    if (kk == 0 && ((kt + ST - 1) & 1) == grp) issue_alt(kbeg + kt + ST - 1, fill);      // stage s is refilled by group s & 1
+                } else {
+                    if (kk == 0) { issue(kbeg + kt + ST - 1, fill); if (NW != 8) issue_w(kbeg + kt + ST - 1, fill); }
+                    else if (NW == 8) issue_w(kbeg + kt + ST - 1, fill);
+                }
             }
             stamp(1 + 3 * kk);                             // 1 / 4: DMA issue
             if constexpr (FM * FN > 16) {
@@ -469,16 +510,16 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
 template <int BM, int BN, int ST, int NW>
 constexpr int ring_lds() { return ST * (BM + BN) * BK * (int)sizeof(half_t); }
 
-template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false>
+template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false, bool ALT = false>
 hipError_t ring_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds<BM, BN, ST, NW>());
 }
 
-template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false>
+template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false, bool ALT = false>
 void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
     constexpr int lds = ring_lds<BM, BN, ST, NW>();
-    fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP>), grid, dim3(NW * 64), lds, a);
+    fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT>), grid, dim3(NW * 64), lds, a);
 }
 
 // ---- tile codes (also the values fie_debug_force_tile / fie_debug_tile_override take)
@@ -493,6 +534,8 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
 //   61 / 62        gemm3_kernel  256x256 x 2 stages / 256x128 x 3 stages, 8 waves
 //   63             gemm3_kernel  256x320 x 2 stages, 8 waves (wave tile 128x80): exactly ONE tile per CU for the FF1 projection M 2048 x N 10240
 //                  (256 tiles) and two rounds for M 8192 x N 5120; 142 FLOP per staged byte pair against 85 for 256x128
+//   64             63 with the two wave groups taking turns at a K-step's LDS-DMA refill (ALT above): FF1 56.5 us against 59.5-63.4 (the same idea on
+//                  256x128 x 3 stages was 3 % SLOWER than 62 and is not built: the barrier still paces both groups by the slower one)
 //   + 1000 / + 2000  force the tile order (n-tiles / m-tiles fastest); plain codes estimate it
 //   95 / 96        gemm3_kernel 51 / 62 with fragment reads one half K-step ahead of the MFMAs (the 4-wave and 2-stage tiles gain nothing from it)
 //   97 / 98 / 94   62 / 96 / 42 with in-kernel cycle stamps (fie_debug_gemm_stamps; slower, for tools/kstep_stamps.py only)
@@ -501,7 +544,7 @@ struct TileDim { int code, bm, bn; };
 constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {42, 128, 64}, {43, 64, 64},
                               {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256},
                               {63, 256, 320}, {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
-                              {52, 128, 128}, {47, 128, 96}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}, {48, 128, 80}};
+                              {52, 128, 128}, {47, 128, 96}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}, {48, 128, 80}, {64, 256, 320}};
 
 // Heuristic tile code for a shape (the default; the autotuner below and the debug hooks can replace it).
 template <int MODE>
@@ -580,6 +623,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     const bool x8 = a.w_scale && a.a_scale != 0.f;           // e4m3 activations x e4m3 weights (gemm_x8.hip): its own tile set
     if (x8) {
         FIE_REQUIRE(dma_ok && !a.A2 && !a.taps2, "fp8 activations: plain GEMM / 3x3 conv views on the LDS-DMA kernels only");
+        if (code == 64) code = 63;                          // no alternating-refill form of the fp8 kernels
         if (MODE == 1 && code == 63) code = 62;
         code = code == 96 || code == 81 || code == 61 ? 62 : code == 95 ? 51 : code == 44 || code == 2 ? 42 : code == 46 || code == 3 || code == 1 ? 43 : code;
         FIE_REQUIRE(code == 42 || code == 43 || code == 47 || code == 51 || code == 52 || code == 54 || code == 62 || code == 63, "tile code %d has no fp8-activation kernel", code);
@@ -633,6 +677,10 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
             FIE_REQUIRE(MODE == 0, "tile code 63 (256x320) is built for the GEMM view only");
             launch_ring<256, 320, 2, 0, 8>(ctx, a, grid);
             break;
+        case 64:
+            FIE_REQUIRE(MODE == 0, "tile code 64 (256x320, alternating refill) is built for the GEMM view only");
+            launch_ring<256, 320, 2, 0, 8, false, false, true>(ctx, a, grid);
+            break;
         case 52: launch_ring<128, 128, 2, M3, 8>(ctx, a, grid); break;
         case 47: launch_ring<128, 96, 3, M3, 4>(ctx, a, grid); break;
         case 48: launch_ring<128, 80, 3, M3, 4>(ctx, a, grid); break;       // weight rows past the packed matrix (80 does not divide Npad) read as zero through the descriptor
@@ -665,7 +713,7 @@ constexpr size_t kFlushBytes = 384u << 20;
 
 template <int MODE>
 int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
-    static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81, 63, 47, 48};      // 47 (128x96): FIE_TUNE_47=0 leaves it out
+    static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81, 63, 47, 48, 64};      // 47 (128x96): FIE_TUNE_47=0 leaves it out
     static const bool use47 = !(getenv("FIE_TUNE_47") && getenv("FIE_TUNE_47")[0] == '0');
     static const int kW8[] = {43, 42, 62, 52, 54};
     static const int kX8[] = {43, 42, 47, 51, 52, 54, 62, 63};
@@ -706,7 +754,7 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     float t_best = t_guess * 0.97f;                          // a challenger has to win by 3 %
     const bool x8 = a.w_scale && a.a_scale != 0.f;
     const int* cand = x8 ? kX8 : a.w_scale ? kW8 : kRing;
-    const int ncand = x8 ? 8 : a.w_scale ? 5 : 12;
+    const int ncand = x8 ? 8 : a.w_scale ? 5 : 13;
     auto excluded = [&](int c) {
         for (int e : ctx->tune_exclude)
             if (e == c) return e != 0;
@@ -717,7 +765,7 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
         if (c == guess || excluded(c)) continue;
         if ((c == 43 || c == 46) && blocks(64, 64) > 64 * ctx->num_cus) continue;       // tens of thousands of tiny tiles: never wins
         if ((c == 81 || c == 96 || c == 62) && 2 * blocks(256, 128) < ctx->num_cus) continue;
-        if (c == 63 && (MODE != 0 || a.N % 320 != 0 || 2 * blocks(256, 320) < ctx->num_cus)) continue;
+        if ((c == 63 || c == 64) && (MODE != 0 || a.N % 320 != 0 || 2 * blocks(256, 320) < ctx->num_cus)) continue;
         if (c == 47 && !use47) continue;
         if (c == 48 && (a.N % 80 != 0 || blocks(128, 80) > 2 * ctx->num_cus)) continue;      // the exact-fit tile of the N = 1280 projections: small grids only
         if (x8 && MODE == 1 && c == 63) continue;
@@ -833,6 +881,7 @@ hipError_t ring_attrs() {
     if (e == hipSuccess) e = ring_attr<256, 256, 2, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<256, 128, 3, MODE, 8>();
     if (e == hipSuccess && MODE == 0) e = ring_attr<256, 320, 2, 0, 8>();
+    if (e == hipSuccess && MODE == 0) e = ring_attr<256, 320, 2, 0, 8, false, false, true>();
     if (e == hipSuccess) e = ring_attr<128, 128, 2, MODE, 8>();
     if (e == hipSuccess) e = ring_attr<128, 96, 3, MODE, 4>();
     if (e == hipSuccess) e = ring_attr<128, 80, 3, MODE, 4>();
