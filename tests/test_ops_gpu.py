@@ -302,7 +302,7 @@ def test_gemm_conv_every_shipped_kernel(fie, code):
         fie.force_tile(0)
     with pytest.raises(hip.FieError, match="unknown tile code"):
         try:
-            fie.force_tile(64)               # a round-1 experiment code: gone
+            fie.force_tile(66)               # never a tile code
             fie.gemm(rnd(64, 64).to(DEV), fie.pack_linear(rnd(64, 64).to(DEV)), 64)
         finally:
             fie.force_tile(0)
