@@ -117,6 +117,13 @@ __global__ __launch_bounds__(NW * 64) void gemm3x8_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // bias row + residual tile ahead of the K loop, as in the f16 ring kernels (gemm_common.h: EpiPre)
+    EpiPre<FM, FN> pre;
+    pre.on = false;
+    if constexpr (FM * FN <= 16) {
+        if (nsplit == 1 && p.epi_prefetch) epilogue_prefetch<FM, FN, WM, WN>(p, pre, m0, n0, wm, wn, lane);
+    }
+
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
         if (s < nk) issue(kbeg + s, s);
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3x8_kernel(GemmArgs p) {
         if constexpr (FN & 1)
             epilogue<FM, 1, WM, WN, true>(p, reinterpret_cast<f32x4(&)[1][FM]>(acc[FN - 1]), m0, n0 + 16 * (FN - 1), wm, wn, lane);
     } else {
-        epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane);
+        epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane, &pre);
     }
 }
 
