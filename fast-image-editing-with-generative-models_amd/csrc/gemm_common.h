@@ -101,6 +101,12 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& p, EpiPre<FM, 
     const int fr = lane & 15, fq = lane >> 4;
     const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
     pre.on = true;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) pre.bias[i] = (u32x2){0u, 0u};                      // absent operands read as zero: the lean epilogue adds them unconditionally
+#pragma unroll
+    for (int j = 0; j < FM; ++j)
+#pragma unroll
+        for (int i = 0; i < FN; ++i) pre.res[j][i] = (u32x2){0u, 0u};
     if (p.bias) {
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.bias), 0, p.N * 2, 0x00020000);
 #pragma unroll
@@ -117,6 +123,34 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& p, EpiPre<FM, 
                 const int n = ncol + i * 16;
                 pre.res[j][i] = __builtin_amdgcn_raw_buffer_load_b64(rs, ro + (n < p.N ? (unsigned)n << 1 : 0xC0000000u), 0, 0);
             }
+        }
+    }
+}
+
+// The LEAN epilogue: (accumulator + bias) + residual -> f16 stores on buffer offsets, the two operands taken from the EpiPre registers (zero when
+// absent), nothing else compiled in.  The full epilogue below is ~25 KB of code behind a dozen uniform branches and runs once per block; for the plain
+// Linear layers of the transformer blocks (no row bias, activation, scale, GEGLU, GroupNorm sums, fp8 or scattered output, split-K) the 6 KB kernel
+// with this epilogue is 0.7-1.2 us per launch faster and gives the same values (tools/fit_probe.py, round 3).  Selected per launch by launch_ring.
+template <int FM, int FN, int WM, int WN>
+__device__ __forceinline__ void epilogue_lean(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane, const EpiPre<FM, FN>& pre) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = mrow + j * 16;
+        const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldc * 2u : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int n = ncol + i * 16;
+            f16x4 b, r, o;
+            __builtin_memcpy(&b, &pre.bias[i], 8);
+            __builtin_memcpy(&r, &pre.res[j][i], 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (half_t)(acc[i][j][q] + (float)b[q] + (float)r[q]);
+            u32x2 bits;
+            __builtin_memcpy(&bits, &o, 8);
+            __builtin_amdgcn_raw_buffer_store_b64(bits, rs_c, ro + (n < p.N ? (unsigned)n << 1 : 0xC0000000u), 0, 0);
         }
     }
 }

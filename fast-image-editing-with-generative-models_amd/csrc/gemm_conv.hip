@@ -173,7 +173,7 @@ __device__ __forceinline__ void read_frags(f16x8 (&f)[N], unsigned addr, std::in
 // A K-step of these kernels is a serial sum -- DMA issue (the waves sit in the 64 B/clk load path) + fragment reads + MFMAs + barrier -- because every
 // wave does the same thing at the same time; with turns, the group that issues nothing goes straight to its reads and MFMAs while the other one feeds the
 // load path, and in the next K-step they swap.
-template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false, bool ALT = false>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0
+template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false, bool ALT = false, bool LEAN = false>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0
 __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     static_assert(!ALT || (NW == 8 && MODE == 0 && !PF && !STAMP), "ALT: 8-wave GEMM-view tiles without the fragment prefetch");
     // waves as 2 (rows) x NW/2 (columns) wherever that leaves whole 16-column fragments; otherwise (128x80) all NW waves stacked along the rows
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     EpiPre<FM, FN> pre;
     pre.on = false;
     if constexpr (FM * FN <= 16) {
-        if (nsplit == 1 && p.epi_prefetch) epilogue_prefetch<FM, FN, WM, WN>(p, pre, m0, n0, wm, wn, lane);
+        if (LEAN || (nsplit == 1 && p.epi_prefetch)) epilogue_prefetch<FM, FN, WM, WN>(p, pre, m0, n0, wm, wn, lane);
     }
 
 #pragma unroll
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         fill = fill + 1 == ST ? 0 : fill + 1;
     }
     stamp(11);                                             // last MFMA group issued
-    if constexpr (FM * FN <= 16) {                         // split-K: only the block that draws the tile's last ticket goes on, with the summed slices
+    if constexpr (FM * FN <= 16 && !LEAN) {                // split-K: only the block that draws the tile's last ticket goes on, with the summed slices
         if (nsplit > 1 && !splitk_reduce<FM, FN, NW>(p, acc, tile_all, slice, tid, smem)) return;
     }
     if constexpr (FM * FN > 16) {                          // 256x256 / 256x320: column chunks of two fragments (register pressure, see gemm8.hip)
@@ -494,7 +494,8 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         if constexpr (FN & 1)
             epilogue<FM, 1, WM, WN, true>(p, reinterpret_cast<f32x4(&)[1][FM]>(acc[FN - 1]), m0, n0 + 16 * (FN - 1), wm, wn, lane);
     } else {
-        epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane, &pre);
+        if constexpr (LEAN) epilogue_lean<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane, pre);
+        else epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane, &pre);
     }
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's stores have left the wave
@@ -510,16 +511,34 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
 template <int BM, int BN, int ST, int NW>
 constexpr int ring_lds() { return ST * (BM + BN) * BK * (int)sizeof(half_t); }
 
+// tiles with <= 16 accumulator fragments per lane have a LEAN instantiation for the GEMM view (gemm_common.h: epilogue_lean)
+template <int BM, int BN, int MODE, int NW, bool STAMP>
+constexpr bool has_lean() { return MODE == 0 && !STAMP && BM * BN / (NW * 64) <= 64; }
+
 template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false, bool ALT = false>
 hipError_t ring_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds<BM, BN, ST, NW>());
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds<BM, BN, ST, NW>());
+    if constexpr (has_lean<BM, BN, MODE, NW, STAMP>()) {
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds<BM, BN, ST, NW>());
+    }
+    return e;
 }
 
 template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false, bool ALT = false>
 void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
     constexpr int lds = ring_lds<BM, BN, ST, NW>();
-    fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT>), grid, dim3(NW * 64), lds, a);
+    if constexpr (has_lean<BM, BN, MODE, NW, STAMP>()) {
+        // a plain Linear (optional bias, optional residual, f16 out): the kernel with the lean epilogue
+        if (a.epi_prefetch && a.splitk <= 1 && !a.rowbias && a.act == FIE_ACT_NONE && a.scale == 1.f && !a.gn_partial && !a.out_f8 && !a.w_scale && !a.oscat &&
+            a.probe == 0) {
+            fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, true>), grid, dim3(NW * 64), lds, a);
+            return;
+        }
+    }
+    fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, false>), grid, dim3(NW * 64), lds, a);
 }
 
 // ---- tile codes (also the values fie_debug_force_tile / fie_debug_tile_override take)

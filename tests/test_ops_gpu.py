@@ -353,6 +353,15 @@ def test_epilogue_operands_loaded_ahead_of_the_k_loop(fie, code):
                 inplace = res.to(DEV).clone()
                 outs.append(fie.gemm(a, w, n, bias=bias, residual=inplace, out=inplace).clone())
             assert torch.equal(outs[0], outs[1]), (code, m, n, k)
+            # the plain-Linear launches take the kernel with the LEAN epilogue (absent operands read as zero): every combination of bias / residual
+            for use_bias, use_res in ((False, False), (True, False), (False, True)):
+                outs = []
+                for pre in (False, True):
+                    fie.epi_prefetch = pre
+                    outs.append(fie.gemm(a, w, n, bias=bias if use_bias else None, residual=res.to(DEV) if use_res else None).clone())
+                assert torch.equal(outs[0], outs[1]), (code, m, n, k, use_bias, use_res)
+                ref = a.float() @ rnd(n, k, seed=n, scale=k ** -0.5).to(DEV).float().T + (bias.float() if use_bias else 0) + (res.to(DEV).float() if use_res else 0)
+                assert rel_err(outs[1], ref) < 3e-3
         x, wc, bias, res = rnd(2, 24, 20, 128, seed=5).to(DEV), fie.pack_conv3x3(rnd(192, 128, 3, 3, seed=6, scale=1152 ** -0.5).to(DEV)), rnd(192, seed=7).to(DEV), rnd(2, 24, 20, 192, seed=8).to(DEV)
         outs = []
         for pre in (False, True):
