@@ -155,6 +155,36 @@ __device__ __forceinline__ void epilogue_lean(const GemmArgs& p, f32x4 (&acc)[FN
     }
 }
 
+// The LEAN GEGLU epilogue of the big tiles (256x320: the FF1 projection): bias + value * gelu(gate) -> f16 pairs, fragment column by fragment column,
+// nothing else compiled in; same arithmetic as the full epilogue with scale 1.  The full path of these tiles inlines the generic epilogue three times.
+template <int FM, int FN, int WM, int WN>
+__device__ __forceinline__ void epilogue_geglu_lean(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)(p.M - 1) * p.ldc + (p.N >> 1)) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.bias), 0, p.bias ? p.N * 2 : 0, 0x00020000);
+    u32x2 bnext = __builtin_amdgcn_raw_buffer_load_b64(rs_b, (unsigned)ncol * 2u, 0, 0);       // no bias: zero-size descriptor, reads zero
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int n = ncol + i * 16;
+        f16x4 b;
+        __builtin_memcpy(&b, &bnext, 8);
+        if (i + 1 < FN) bnext = __builtin_amdgcn_raw_buffer_load_b64(rs_b, (unsigned)(ncol + (i + 1) * 16) * 2u, 0, 0);      // one fragment column ahead: 160 accumulator registers leave no room for all five
+        const unsigned co = n < p.N ? (unsigned)n : 0xC0000000u;          // output column n / 2, two bytes each: byte offset n
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = mrow + j * 16;
+            const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldc * 2u : 0x80000000u;
+            f16x2 o;
+            o[0] = (half_t)((acc[i][j][0] + (float)b[0]) * fie_gelu(acc[i][j][1] + (float)b[1]) * 1.0f);
+            o[1] = (half_t)((acc[i][j][2] + (float)b[2]) * fie_gelu(acc[i][j][3] + (float)b[3]) * 1.0f);
+            unsigned bits;
+            __builtin_memcpy(&bits, &o, 4);
+            __builtin_amdgcn_raw_buffer_store_b32(bits, rs_c, ro + co, 0, 0);
+        }
+    }
+}
+
 template <int FM, int FN, int WM, int WN, bool BUF = false>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane, const EpiPre<FM, FN>* pre = nullptr) {
     const int fr = lane & 15, fq = lane >> 4;

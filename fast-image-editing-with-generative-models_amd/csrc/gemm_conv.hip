@@ -488,11 +488,15 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         if (nsplit > 1 && !splitk_reduce<FM, FN, NW>(p, acc, tile_all, slice, tid, smem)) return;
     }
     if constexpr (FM * FN > 16) {                          // 256x256 / 256x320: column chunks of two fragments (register pressure, see gemm8.hip)
+        if (p.act == FIE_ACT_GEGLU && p.epi_prefetch && !p.rowbias && !p.res && p.scale == 1.f && !p.gn_partial && !p.out_f8 && !p.w_scale && !p.oscat && p.probe == 0) {
+            epilogue_geglu_lean<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);         // the FF1 projection: compact code instead of three generic epilogues
+        } else {
 #pragma unroll
         for (int c = 0; c < FN / 2; ++c)
             epilogue<FM, 2, WM, WN, true>(p, reinterpret_cast<f32x4(&)[2][FM]>(acc[2 * c]), m0, n0 + 32 * c, wm, wn, lane);
         if constexpr (FN & 1)
             epilogue<FM, 1, WM, WN, true>(p, reinterpret_cast<f32x4(&)[1][FM]>(acc[FN - 1]), m0, n0 + 16 * (FN - 1), wm, wn, lane);
+        }
     } else {
         if constexpr (LEAN) epilogue_lean<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane, pre);
         else epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane, &pre);
