@@ -495,6 +495,7 @@ int fie_attn_init(void) {
     if (e == hipSuccess) e = attn_attrs<64, 2, 64>();
     if (e == hipSuccess) e = attn_attrs<64, 1, 64>();
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<64, 2, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * (int)sizeof(half_t));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<64, 1, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 96 * 64 * (int)sizeof(half_t));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<64, 1, 64, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 64 * (int)sizeof(half_t));
     if (e != hipSuccess) {
         fie_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -533,6 +534,9 @@ static int attention_impl(fie_ctx* ctx, const void* Q, int64_t ldq, const void* 
     // 4096-token maps (the round-2 rule) 15.40-15.44 ms, whether the small maps run 4 x 16 or 2 x 32 -- so 128-query blocks only for grids of
     // four and more waves of them (batched jobs), where the round-2 measurements were taken
     if (blocks128 >= ctx->num_cus * 4) return launch_attn2<64, 2, 64>(ctx, a, B);
+    // cross-attention over the 77 text tokens: ONE 96-key tile instead of two 64-key tiles (the second one 13 keys wide): no second pass through the
+    // wait / barrier / softmax-rescale machinery of the key loop (round 3: 7.9 -> see profiles/README.md)
+    if (Tk <= 96 && !causal && ctx->attn_variant == 0) return launch_attn2<64, 1, 96>(ctx, a, B);
     return launch_attn2<64, 1, 64>(ctx, a, B);
 }
 
