@@ -155,6 +155,32 @@ __device__ __forceinline__ void epilogue_lean(const GemmArgs& p, f32x4 (&acc)[FN
     }
 }
 
+// LEAN epilogue of the fp8-activation kernels (gemm_x8.hip): the same with the per-output-channel dequantisation scale in front (acc * (w_scale * a_scale))
+template <int FM, int FN, int WM, int WN>
+__device__ __forceinline__ void epilogue_lean_scaled(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane, const EpiPre<FM, FN>& pre,
+                                                     const f32x4 (&ws)[FN]) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = mrow + j * 16;
+        const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldc * 2u : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int n = ncol + i * 16;
+            f16x4 b, r, o;
+            __builtin_memcpy(&b, &pre.bias[i], 8);
+            __builtin_memcpy(&r, &pre.res[j][i], 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (half_t)((acc[i][j][q] * (ws[i][q] * p.a_scale) + (float)b[q]) + (float)r[q]);
+            u32x2 bits;
+            __builtin_memcpy(&bits, &o, 8);
+            __builtin_amdgcn_raw_buffer_store_b64(bits, rs_c, ro + (n < p.N ? (unsigned)n << 1 : 0xC0000000u), 0, 0);
+        }
+    }
+}
+
 // The LEAN GEGLU epilogue of the big tiles (256x320: the FF1 projection): bias + value * gelu(gate) -> f16 pairs, fragment column by fragment column,
 // nothing else compiled in; same arithmetic as the full epilogue with scale 1.  The full path of these tiles inlines the generic epilogue three times.
 template <int FM, int FN, int WM, int WN>

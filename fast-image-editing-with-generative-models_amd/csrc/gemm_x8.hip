@@ -21,7 +21,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int KE = 128;                   // k-values per K-step (one 128-byte row)
 constexpr int kUnitScale = 0x7F7F7F7F;    // E8M0 127 in every byte: block scale 2^0
 
-template <int BM, int BN, int ST, int NW, int MODE = 0>      // MODE 0 = GEMM view, 2 = 3x3 conv view (im2col of an NHWC e4m3 tensor, Cin % 128 == 0)
+template <int BM, int BN, int ST, int NW, int MODE = 0, bool LEAN = false>      // MODE 0 = GEMM view, 2 = 3x3 conv view (im2col of an NHWC e4m3 tensor, Cin % 128 == 0); LEAN: gemm_common.h epilogue_lean_scaled
 __global__ __launch_bounds__(NW * 64) void gemm3x8_kernel(GemmArgs p) {
     constexpr int WGN = NW / 2;
     constexpr int WM = BM / 2, WN = BN / WGN;
@@ -121,7 +121,13 @@ __global__ __launch_bounds__(NW * 64) void gemm3x8_kernel(GemmArgs p) {
     EpiPre<FM, FN> pre;
     pre.on = false;
     if constexpr (FM * FN <= 16) {
-        if (nsplit == 1 && p.epi_prefetch) epilogue_prefetch<FM, FN, WM, WN>(p, pre, m0, n0, wm, wn, lane);
+        if (LEAN || (nsplit == 1 && p.epi_prefetch)) epilogue_prefetch<FM, FN, WM, WN>(p, pre, m0, n0, wm, wn, lane);
+    }
+    f32x4 ws[LEAN ? FN : 1];                                     // LEAN: the dequantisation scales of the lane's columns ride along with the bias row
+    if constexpr (LEAN) {
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_scale), 0, p.N * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) ws[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (unsigned)(n0 + wn * WN + i * 16 + (lane >> 4) * 4) * 4u, 0, 0));
     }
 
 #pragma unroll
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3x8_kernel(GemmArgs p) {
         stage = stage + 1 == ST ? 0 : stage + 1;
         fill = fill + 1 == ST ? 0 : fill + 1;
     }
-    if constexpr (FM * FN <= 16) {
+    if constexpr (FM * FN <= 16 && !LEAN) {
         if (nsplit > 1 && !splitk_reduce<FM, FN, NW>(p, acc, tile_all, slice, tid, smx)) return;
     }
     if constexpr (FM * FN > 16) {
@@ -172,16 +178,24 @@ __global__ __launch_bounds__(NW * 64) void gemm3x8_kernel(GemmArgs p) {
         if constexpr (FN & 1)
             epilogue<FM, 1, WM, WN, true>(p, reinterpret_cast<f32x4(&)[1][FM]>(acc[FN - 1]), m0, n0 + 16 * (FN - 1), wm, wn, lane);
     } else {
-        epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane, &pre);
+        if constexpr (LEAN) epilogue_lean_scaled<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane, pre, ws);
+        else epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane, &pre);
     }
 }
 
 template <int BM, int BN, int ST>
 constexpr int x8_lds() { return ST * (BM + BN) * 128; }
 
+template <int BM, int BN, int NW>
+constexpr bool x8_has_lean() { return BM * BN / (NW * 64) <= 64; }
+
 template <int BM, int BN, int ST, int NW>
 hipError_t x8_attr() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3x8_kernel<BM, BN, ST, NW, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, x8_lds<BM, BN, ST>());
+    if constexpr (x8_has_lean<BM, BN, NW>()) {
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3x8_kernel<BM, BN, ST, NW, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, x8_lds<BM, BN, ST>());
+    }
     if (e == hipSuccess && BN != 320)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3x8_kernel<BM, BN, ST, NW, BN == 320 ? 0 : 2>), hipFuncAttributeMaxDynamicSharedMemorySize, x8_lds<BM, BN, ST>());
     return e;
@@ -190,7 +204,16 @@ hipError_t x8_attr() {
 template <int BM, int BN, int ST, int NW>
 void launch_x8(fie_ctx* ctx, const GemmArgs& a, dim3 grid, int conv) {
     if (conv) fie_launch(ctx, (gemm3x8_kernel<BM, BN, ST, NW, BN == 320 ? 0 : 2>), grid, dim3(NW * 64), x8_lds<BM, BN, ST>(), a);
-    else fie_launch(ctx, (gemm3x8_kernel<BM, BN, ST, NW, 0>), grid, dim3(NW * 64), x8_lds<BM, BN, ST>(), a);
+    else {
+        if constexpr (x8_has_lean<BM, BN, NW>()) {
+            // a plain Linear on e4m3 activations (optional bias / residual, f16 out): the kernel with the lean epilogue
+            if (a.epi_prefetch && a.splitk <= 1 && !a.rowbias && a.act == FIE_ACT_NONE && a.scale == 1.f && !a.gn_partial && !a.out_f8 && !a.oscat && a.probe == 0) {
+                fie_launch(ctx, (gemm3x8_kernel<BM, BN, ST, NW, 0, true>), grid, dim3(NW * 64), x8_lds<BM, BN, ST>(), a);
+                return;
+            }
+        }
+        fie_launch(ctx, (gemm3x8_kernel<BM, BN, ST, NW, 0>), grid, dim3(NW * 64), x8_lds<BM, BN, ST>(), a);
+    }
 }
 
 // ---- e4m3 conversion of an fp16 activation tensor (tests, and producers that have no fused form): y = sat(x * inv_scale)

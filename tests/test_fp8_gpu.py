@@ -165,6 +165,16 @@ def test_gemm_x8_fp8_activations_matches_quantised_reference(fie8, code):
         wq = wp.q.view(torch.float8_e4m3fn).float().cpu()[:n, :k]
         lin = (aq @ wq.T) * 2.0 * wp.scale[:n].cpu() + bias.float() + rb.float().repeat_interleave((m + 1) // 2, 0)[:m]
         assert rel_err(out, F.silu(lin) * 0.5 + res.float()) < 2e-3, (m, n, k)
+        # a plain Linear (bias / residual optional, f16 out) takes the kernel with the LEAN epilogue: the full epilogue's values to rounding, and the reference's
+        for use_bias, use_res in ((True, True), (False, False), (True, False)):
+            outs = []
+            for pre in (False, True):
+                fie8.epi_prefetch = pre
+                outs.append(fie8.gemm(a8, wp, n, bias=bias.to(DEV) if use_bias else None, residual=res.to(DEV) if use_res else None, a_scale=2.0).clone())
+            fie8.epi_prefetch = True
+            # (not bit for bit: the lean form's scale-multiply and bias-add may contract into one FMA where the full epilogue's do not; one rounding apart)
+            assert rel_err(outs[1], outs[0].float()) < 1e-3, (m, n, k, use_bias, use_res)
+            assert rel_err(outs[1], (aq @ wq.T) * 2.0 * wp.scale[:n].cpu() + (bias.float() if use_bias else 0) + (res.float() if use_res else 0)) < 2e-3
         # e4m3 output (what a following fp8-activation GEMM reads): value / 4, saturated
         o8 = fie8.gemm(a8, wp, n, bias=bias.to(DEV), a_scale=2.0, out_f8=True, out_inv_scale=0.25)
         assert o8.dtype == torch.uint8 and o8.shape == (m, n)
