@@ -23,6 +23,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 PEAK_TF, PEAK_GB = 2500.0, 8000.0
+# LDS-fill traffic of the tiled kernels: every K-step of 64 stages (BM + BN) x 128 B per tile out of the XCD's L2.  MI355X_MICROARCH.md ("Indexed rows: gather into
+# LDS") measures 66-73 GB/s per CU = 16.8-18.8 TB/s chip-wide for such fills: the bound of the small tiles (BM BN / (BM + BN) FLOP per staged byte).
+TILE = {1: (128, 128), 2: (128, 64), 3: (64, 64), 42: (128, 64), 43: (64, 64), 44: (128, 64), 46: (64, 64), 47: (128, 96), 48: (128, 80), 51: (128, 128), 52: (128, 128),
+        54: (192, 128), 61: (256, 256), 62: (256, 128), 63: (256, 320), 64: (256, 320), 81: (256, 256), 82: (256, 256), 95: (128, 128), 96: (256, 128)}
+FILL_TB = 17.8
+
+
+def staged_bytes(desc):
+    """LDS-fill bytes of one GEMM / conv launch from its log description, or None."""
+    m = re.search(r"M=(\d+) N=(\d+) K=(\d+).* code=(\d+)", desc)
+    if not m:
+        return None
+    M, N, K, code = (int(v) for v in m.groups())
+    t = TILE.get(code % 1000)
+    if t is None:
+        return None
+    bm, bn = t
+    return -(-M // bm) * -(-N // bn) * -(-K // 64) * (bm + bn) * 128.0
 
 
 def run(out_path, model="ssd-1b"):
@@ -120,7 +138,9 @@ def report(d, out_md):
         f.write("## By stage (kernel time, single stream)\n\n| stage | ms |\n|---|---:|\n")
         for k, v in stage_us.items():
             f.write(f"| {k} | {v / 1e3:.2f} |\n")
-        f.write("\n## By problem, largest first\n\n| problem | kernel | blocks | launches | avg us | min us | total us | % | rate | frac of bound |\n|---|---|---:|---:|---:|---:|---:|---:|---:|---:|\n")
+        f.write("\nLast column: LDS-fill traffic of the tiled kernels (tiles x K-steps x (BM + BN) x 128 B) over the launch's time, against the ~17.8 TB/s at which the 256 CUs can fill "
+                "LDS out of their L2s (MI355X_MICROARCH.md: 66-73 GB/s per CU): the bound the small-tile GEMMs run into long before the MFMA peak.\n")
+        f.write("\n## By problem, largest first\n\n| problem | kernel | blocks | launches | avg us | min us | total us | % | rate | frac of bound | LDS fill TB/s (frac of 17.8) |\n|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
         classes = {}
         for (desc, short, blocks, lds), e in sorted(per.items(), key=lambda kv: -kv[1]["us"]):
             avg = e["us"] / e["n"]
@@ -130,8 +150,10 @@ def report(d, out_md):
                 rate, frac = f"{e['bytes'] / avg / 1e3:.0f} GB/s", e["bytes"] / avg / 1e3 / PEAK_GB
             else:
                 rate, frac = "", None
+            sb = staged_bytes(desc)
+            fill = "" if sb is None else f"{sb / avg / 1e6:.1f} ({sb / avg / 1e6 / FILL_TB:.2f})"
             f.write(f"| {desc} | `{short}` | {blocks} | {e['n']} | {avg:.1f} | {e['mn']:.1f} | {e['us']:.0f} | {100 * e['us'] / tot:.1f} | {rate} | "
-                    f"{'' if frac is None else f'{frac:.3f}'} |\n")
+                    f"{'' if frac is None else f'{frac:.3f}'} | {fill} |\n")
             cls = desc.split(" ")[0] if desc else short
             m = re.search(r"M=(\d+)", desc)
             if cls in ("gemm", "conv") and m:
