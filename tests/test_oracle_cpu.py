@@ -200,6 +200,40 @@ def test_canny_oracle_properties():
     assert np.array_equal(ocanny.canny_rgb(step, 200, 100), e)   # thresholds are swapped when reversed
 
 
+def test_ssim_against_an_independent_float64_restatement():
+    """SSIM (reference src/metrics.py:227-239 -> torchmetrics StructuralSimilarityIndexMeasure(data_range=1.0): 11x11 Gaussian, sigma 1.5, k1 0.01,
+    k2 0.03, reflect pad then crop, mean over the map -- torchmetrics is not installable here, so this is NOT a pin against it) checked against a second,
+    independent code path: separable float64 correlation with scipy.ndimage on the un-padded image, evaluated only where the window never touches the
+    border (the region torchmetrics keeps after its crop), formula straight from Wang et al. 2004 eq. 13.  Known answers: SSIM(a, a) = 1; a constant
+    image against another constant has SSIM = luminance term (2 mu_x mu_y + c1) / (mu_x^2 + mu_y^2 + c1)."""
+    from PIL import Image
+    from scipy.ndimage import correlate1d
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 255, (96, 80, 3), dtype=np.uint8)
+    other = (base.astype(int) + rng.integers(-25, 25, base.shape)).clip(0, 255).astype(np.uint8)
+
+    def ssim64(u8a, u8b):
+        x, y = u8a.astype(np.float64) / 255.0, u8b.astype(np.float64) / 255.0
+        d = np.arange(-5, 6, dtype=np.float64)
+        g = np.exp(-(d / 1.5) ** 2 / 2)
+        g /= g.sum()
+        blur = lambda t: correlate1d(correlate1d(t, g, axis=0, mode="constant"), g, axis=1, mode="constant")[5:-5, 5:-5]
+        c1, c2 = 0.01 ** 2, 0.03 ** 2
+        vals = []
+        for ch in range(3):
+            mx, my = blur(x[..., ch]), blur(y[..., ch])
+            sxx, syy, sxy = blur(x[..., ch] ** 2) - mx * mx, blur(y[..., ch] ** 2) - my * my, blur(x[..., ch] * y[..., ch]) - mx * my
+            vals.append(((2 * mx * my + c1) * (2 * sxy + c2)) / ((mx * mx + my * my + c1) * (sxx + syy + c2)))
+        return float(np.mean(vals))
+
+    got = ometrics.ssim(Image.fromarray(base), Image.fromarray(other), size=None)
+    assert abs(got - ssim64(base, other)) < 2e-5, (got, ssim64(base, other))
+    flat_a, flat_b = np.full((64, 64, 3), 100, np.uint8), np.full((64, 64, 3), 140, np.uint8)
+    mx, my, c1 = 100 / 255.0, 140 / 255.0, 1e-4
+    # both variances are zero: the structure term is c2 / c2 = 1 and only the luminance term remains (to fp32 cancellation in E[x^2] - mu^2 against c2 = 9e-4)
+    assert abs(ometrics.ssim(Image.fromarray(flat_a), Image.fromarray(flat_b), size=None) - (2 * mx * my + c1) / (mx * mx + my * my + c1)) < 5e-4
+
+
 def test_ssim_oracle_and_product_metrics_agree():
     from PIL import Image
     from src.metrics import MetricsCalculator
