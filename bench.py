@@ -105,8 +105,9 @@ def _graph_ms(fn, reps=5):
     path (hipGraph replay) spends on them, without the host's per-launch cost that an eager pass adds to chains of small kernels."""
     fn()                                                # eager warm-up: lazy workspaces; tiles were tuned by the edits before
     torch.cuda.synchronize()
+    from fie_amd import hip
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=hip.context(torch.cuda.current_device()).capture_stream()):   # split-K workspace bound before the capture
         out = fn()
     g.replay()
     torch.cuda.synchronize()

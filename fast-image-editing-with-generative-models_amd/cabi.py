@@ -88,6 +88,7 @@ def vae_encode(vae, x):
     """x: [1, H, W, 8] f16 -> moments [H/8 * W/8, 8] through fie_vae_encode_f16."""
     ctx = vae.ctx
     ctx.sync_stream()
+    ctx._bind_splitk()              # the walk's GEMMs / convs split K on the ctx-bound workspace: this stream's own (include/fie.h)
     _, hh, ww, _ = x.shape
     down = 2 ** (len(vae.cfg["block_out_channels"]) - 1)
     vc = vae_config(vae.cfg, hh // down, ww // down)
@@ -103,6 +104,7 @@ def vae_decode(vae, z):
     """z: [1, h, w, 8] f16 -> [1, 8h, 8w, 4] f16 through fie_vae_decode_f16."""
     ctx = vae.ctx
     ctx.sync_stream()
+    ctx._bind_splitk()              # the walk's GEMMs / convs split K on the ctx-bound workspace: this stream's own (include/fie.h)
     _, h, w, _ = z.shape
     vc = vae_config(vae.cfg, h, w)
     need = hip.lib().fie_vae_decode_workspace_bytes(ctypes.byref(vc), h, w)
@@ -134,6 +136,7 @@ def clip_forward(clip, prefix, ids, eos_rows=None):
     """ids: int32 [B, T] on the device; eos_rows: int32 [B] row indices (needed with a projection) -> (penultimate [B*T, C], pooled [B, P] | None)."""
     ctx, cfg = clip.ctx, clip.cfg
     ctx.sync_stream()
+    ctx._bind_splitk()              # the walk's GEMMs / convs split K on the ctx-bound workspace: this stream's own (include/fie.h)
     b, t = ids.shape
     cc = hip.ClipConfig(b, t, cfg["hidden"], cfg["heads"], cfg["layers"], cfg["intermediate"], cfg["projection_dim"] or 0,
                         1 if cfg["act"] == "quick_gelu" else 0, cfg["eps"])
@@ -248,6 +251,7 @@ def controlnet_forward(cn, prefix, x, t, text, pooled, time_ids, cond, scale):
     """x [B, h, w, 8] f16, t f32 [B], text [B*T, X] f16, pooled [B, P] f16, time_ids f32 [B, 6], cond [B, 8h, 8w, 8] f16 -> (down residuals, mid residual)."""
     ctx = cn.ctx
     ctx.sync_stream()
+    ctx._bind_splitk()              # the walk's GEMMs / convs split K on the ctx-bound workspace: this stream's own (include/fie.h)
     b, h, w, _ = x.shape
     uc = unet_config(cn.cfg, b, h, w, text.shape[0] // b)
     need = hip.lib().fie_controlnet_workspace_bytes(ctypes.byref(uc))
@@ -267,6 +271,7 @@ def unet_forward(unet, prefix, x, t, text, pooled, time_ids, down_residuals=None
     """-> eps [B, h, w, 4] f16 through fie_unet_forward_f16."""
     ctx = unet.ctx
     ctx.sync_stream()
+    ctx._bind_splitk()              # the walk's GEMMs / convs split K on the ctx-bound workspace: this stream's own (include/fie.h)
     b, h, w, _ = x.shape
     uc = unet_config(unet.cfg, b, h, w, text.shape[0] // b)
     need = hip.lib().fie_unet_workspace_bytes(ctypes.byref(uc))

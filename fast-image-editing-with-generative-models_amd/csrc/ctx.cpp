@@ -111,17 +111,38 @@ int fie_program_begin(fie_ctx* ctx, fie_program** out) {
     return FIE_OK;
 }
 
+// `done` marks the end of the program's latest pass on `stream` (not under stream capture: a captured event cannot order eager work)
+static void program_mark_done(fie_program* p, hipStream_t stream) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    if (!p->done && hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); p->done = nullptr; return; }
+    if (hipEventRecord(p->done, stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    p->has_done = true;
+    p->last_stream = stream;
+}
+
 int fie_program_end(fie_ctx* ctx) {
     FIE_REQUIRE(ctx && ctx->recording, "fie_program_end: nothing is being recorded");
+    program_mark_done(ctx->recording, ctx->stream);         // the recording pass executed on this stream
     ctx->recording = nullptr;
     return FIE_OK;
 }
 
 int fie_program_launches(const fie_program* p) { return p ? (int)p->recs.size() : -1; }
 
-int fie_program_run(fie_ctx* ctx, const fie_program* p) {
+int fie_program_run(fie_ctx* ctx, fie_program* p) {
     FIE_REQUIRE(ctx && p, "fie_program_run: NULL argument");
     FIE_REQUIRE(ctx->recording != p, "fie_program_run: the program is still being recorded");
+    // A program must not be in flight twice (frozen buffers, frozen split-K workspace): a run on ANOTHER stream than its previous pass
+    // first waits for that pass.  Under stream capture nothing is ordered here: the captured graph inherits the rule (include/fie.h).
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool eager = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+        if (eager && p->has_done && p->last_stream != ctx->stream && hipStreamWaitEvent(ctx->stream, p->done, 0) != hipSuccess) {
+            fie_set_error("fie_program_run: hipStreamWaitEvent failed: %s", hipGetErrorString(hipGetLastError()));
+            return FIE_EHIP;
+        }
+    }
     void* argv[64];
     for (const fie_launch_rec& r : p->recs) {
         FIE_REQUIRE(r.offs.size() <= 64, "fie_program_run: too many kernel arguments");
@@ -133,6 +154,7 @@ int fie_program_run(fie_ctx* ctx, const fie_program* p) {
         }
         if (ctx->recording) ctx->recording->recs.push_back(r);       // programs nest: running one while recording another copies it in
     }
+    program_mark_done(p, ctx->stream);
     return FIE_OK;
 }
 
@@ -140,6 +162,7 @@ int fie_program_destroy(fie_ctx* ctx, fie_program* p) {
     if (ctx)
         for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();)
             it = it->second == p ? ctx->graphs.erase(it) : std::next(it);
+    if (p && p->done) (void)hipEventDestroy(p->done);
     delete p;
     return FIE_OK;
 }

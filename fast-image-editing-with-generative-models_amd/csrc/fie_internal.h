@@ -32,6 +32,12 @@ struct fie_launch_rec {
 };
 struct fie_program {
     std::vector<fie_launch_rec> recs;
+    // ordering of a program against ITSELF (round 4): its launches carry frozen pointers (static buffers, the split-K workspace that was
+    // bound while it was recorded), so two copies in flight on different streams would race on them.  `done` is recorded behind the
+    // recording pass and behind every run; a run on another stream than the previous one waits for it first (ctx.cpp: fie_program_run)
+    hipEvent_t done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_done = false;
 };
 
 struct fie_weight { const void* ptr; int64_t n, ld; };    // fie_weights_register: a packed device tensor under its diffusers parameter name

@@ -51,7 +51,12 @@ struct GemmArgs {
     // ldc counts bytes): the consumer GEMM reads it without any conversion
     float a_scale; int out_f8; float out_inv_scale;
     int order;                              // 0: n-tiles fastest (an XCD owns a range of rows), 1: m-tiles fastest (an XCD owns a range of columns)
+    // halo-resident conv (conv_halo.hip): a tile is a 16x16 PATCH of one image's output pixels, not 256 consecutive rows.  Fragment j of a wave
+    // (16 pixels of one patch row) then starts frag_ld = OW rows after fragment j - 1 instead of 16: the epilogue's row of fragment (wm, j), lane fr
+    // is m0 + (wm * FM + j) * frag_ld + fr with m0 = the patch's first pixel.  0 = the ordinary consecutive-row tile (16).
+    int frag_ld;
 };
+__device__ __forceinline__ int frag_ld_of(const GemmArgs& p) { return p.frag_ld ? p.frag_ld : 16; }
 
 // oscat == 2: the block's parity comes from its (remapped) tile id; the four parity tiles of one output tile are neighbours in time and
 // share the input rows in L2.  Rewrites the by-value kernel argument and returns the tile id within the parity.
@@ -99,7 +104,8 @@ struct EpiPre {
 template <int FM, int FN, int WM, int WN>
 __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& p, EpiPre<FM, FN>& pre, int m0, int n0, int wm, int wn, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
-    const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
+    const int fld = frag_ld_of(p);
+    const int mrow = m0 + wm * FM * fld + fr, ncol = n0 + wn * WN + fq * 4;
     pre.on = true;
 #pragma unroll
     for (int i = 0; i < FN; ++i) pre.bias[i] = (u32x2){0u, 0u};                      // absent operands read as zero: the lean epilogue adds them unconditionally
@@ -116,7 +122,7 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& p, EpiPre<FM, 
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.res), 0, (int)(((int64_t)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
-            const int m = mrow + j * 16;
+            const int m = mrow + j * fld;
             const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldr * 2u : 0x80000000u;
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
@@ -217,15 +223,16 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
     const bool have_pre = pre != nullptr && pre->on;
     if (p.probe == 4 && p.M > 0) return;                    // timing probe: no epilogue at all (p.M > 0 keeps the accumulators live)
     const bool geglu = p.act == FIE_ACT_GEGLU;
-    const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
+    const int fld = frag_ld_of(p);                          // rows between consecutive fragments: 16, or OW for a 16x16 output patch (GemmArgs::frag_ld)
+    const int mrow = m0 + wm * FM * fld + fr, ncol = n0 + wn * WN + fq * 4;
     // clamped coordinates for the loads of the pointer form; BUF: byte offsets, out of range where the lane is outside the matrix
     auto col = [&](int i) { const int n = ncol + i * 16; return n < p.N ? n : p.N - 4; };       // N % 4 == 0
-    auto row = [&](int j) { const int m = mrow + j * 16; return m < p.M ? m : p.M - 1; };
+    auto row = [&](int j) { const int m = mrow + j * fld; return m < p.M ? m : p.M - 1; };
     constexpr unsigned kRowOut = 0x80000000u, kColOut = 0xC0000000u;    // any sum with a span <= 1 GiB stays out of range
     auto coff = [&](int i, bool half) { const int n = ncol + i * 16; return n < p.N ? (unsigned)n << (half ? 0 : 1) : kColOut; };   // bytes; half (GEGLU): output column n / 2
-    auto roff = [&](int j, int64_t ld) { const int m = mrow + j * 16; return m < p.M ? (unsigned)m * (unsigned)ld * 2u : kRowOut; };
+    auto roff = [&](int j, int64_t ld) { const int m = mrow + j * fld; return m < p.M ? (unsigned)m * (unsigned)ld * 2u : kRowOut; };
     auto coff_row = [&](int j) {                            // byte offset of output row j in C: scattered for the parity convs of a 2x upsampling
-        const int m = mrow + j * 16;
+        const int m = mrow + j * fld;
         if (m >= p.M) return kRowOut;
         if (!p.oscat) return (unsigned)m * (unsigned)p.ldc * 2u;
         const int hw = p.OH * p.OW, b = m / hw, rem = m - b * hw, oh = rem / p.OW, ow = rem - oh * p.OW;
@@ -326,7 +333,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
             for (int i = 0; i < FN; ++i) sum[i] = sq[i] = 0.f;
 #pragma unroll
             for (int dj = 0; dj < 2; ++dj) {
-                const bool ok = mrow + (2 * jj + dj) * 16 < p.M;
+                const bool ok = mrow + (2 * jj + dj) * fld < p.M;
 #pragma unroll
                 for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -336,8 +343,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
                         sq[i] += x * x;
                     }
             }
-            const int mg = m0 + wm * WM + jj * 32;          // first row of the granule (wave-uniform)
-            const int b = mg / p.gn_rows, chunk = p.gn_chunk0 + ((mg - b * p.gn_rows) >> 5);
+            const int mg = m0 + (wm * FM + 2 * jj) * fld;   // first row of the granule (wave-uniform)
+            const int b = mg / p.gn_rows, rem = mg - b * p.gn_rows;
+            // granule id within the image: 32 consecutive rows, or (patch tiles) two 16-pixel runs one image row apart -- any one-to-one numbering
+            // of an image's rows / 32 granules serves: the consumer only sums over them
+            const int chunk = p.gn_chunk0 + (p.frag_ld ? ((rem / p.frag_ld) >> 1) * (p.frag_ld >> 4) + ((rem % p.frag_ld) >> 4) : rem >> 5);
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 // 16 rows: four DPP adds (xor 1, xor 2, mirror in 8, mirror in 16) leave the row-of-16 total in every lane, VALU only;
@@ -369,7 +379,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
             auto q = [&](float x) { return fminf(fmaxf(x * inv, -448.f), 448.f); };
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
-                const int m = mrow + j * 16;
+                const int m = mrow + j * fld;
                 const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldc : kRowOut;
 #pragma unroll
                 for (int i = 0; i < FN; ++i) {
@@ -391,7 +401,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
     const __amdgpu_buffer_rsrc_t rs_c = rsrc(p.C, BUF ? ((int64_t)(p.oscat ? 4 * (int64_t)p.M : p.M) - 1) * p.ldc * 2 + (geglu ? p.N >> 1 : p.N) * 2 : 0);
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
-        const int m = mrow + j * 16;
+        const int m = mrow + j * fld;
         const unsigned ro = coff_row(j);
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
@@ -445,7 +455,8 @@ __device__ __forceinline__ void wait_vm_barrier() {
 // accumulators as whole 16-byte lane vectors ([fragment][thread]: 1 KiB per wave instruction) with sc1 (write-through) stores, every wave
 // drains its stores, the workgroup meets at a barrier and ONE lane adds to the tile's arrival counter (relaxed, agent scope).  Nobody
 // ever waits for another block (no residency assumption, no deadlock with other streams' kernels on the chip): the block whose add
-// returns splitk - 1 is the reducer.  It resets the counter for the next launch (counters start zeroed: fie_splitk_workspace), makes
+// returns splitk - 1 (mod splitk) is the reducer.  It subtracts splitk from the counter (counters start zeroed: fie_splitk_workspace; every
+// launch leaves them zero), makes
 // one agent-scope acquire and reads ALL slices (its own included: no per-slice branch) in slice order with sc1 loads, so the sum
 // does not depend on which block came last.  Returns true in the reducer, whose accumulators then hold the full sums.
 template <int FM, int FN, int NW>
@@ -466,9 +477,15 @@ __device__ __forceinline__ bool splitk_reduce(const GemmArgs& p, f32x4 (&acc)[FN
     volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(lds);   // the ring is drained: reuse its first word (one LDS object only)
     if (tid == 0) *flag = __hip_atomic_fetch_add(p.sk_tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (*flag != (unsigned)(S - 1)) return false;
+    // Every S-th arrival reduces, and it takes its S arrivals back OFF the counter with one atomic subtract (round 4; was: "== S - 1, then
+    // store 0").  A subtract of S never changes the counter mod S, so arrival k always sees k mod S whatever interleaves with it, and the
+    // counter returns to zero after any whole number of launches: a counter can no longer be left stuck by a caller that breaks the
+    // one-launch-in-flight-per-workspace rule (include/fie.h, "split-K workspace") -- the sums of THOSE overlapping launches are still
+    // undefined, but every later launch on the workspace is sound again.  (The store-0 form left the counter at 1 forever after two
+    // interleaved copies of one launch: GPUTEST r03.)
+    if (*flag % (unsigned)S != (unsigned)(S - 1)) return false;
     if (tid == 0) {
-        __hip_atomic_store(p.sk_tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_sub(p.sk_tickets + tile, (unsigned)S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

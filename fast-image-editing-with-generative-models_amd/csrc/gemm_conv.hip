@@ -1029,6 +1029,29 @@ int fie_gemm_autotune_report(fie_ctx* ctx, char* buf, int cap) {
     return (int)ctx->tuned.size();
 }
 
+// The inverse of fie_gemm_autotune_report: remembered choices from its text (one "gemm|conv M= N= K= K1= geom= w8= -> code" line per problem; other
+// lines are skipped).  A host saves the report of a tuned process and loads it into the next one: no timing launches at start-up, and the SAME kernels
+// (a split-K choice is visible in the last f16 bit) on every box.  Entries replace remembered ones for the same problem.  Returns the number loaded.
+int fie_gemm_autotune_load(fie_ctx* ctx, const char* text) {
+    FIE_REQUIRE(ctx != nullptr && text != nullptr, "fie_gemm_autotune_load: NULL argument");
+    int n = 0;
+    for (const char* q = text; *q;) {
+        char kind[8] = "";
+        fie_tune_key k{};
+        int code = 0;
+        if (sscanf(q, "%7s M=%d N=%d K=%d K1=%d geom=%d w8=%d -> %d", kind, &k.M, &k.N, &k.K, &k.K1, &k.geom, &k.w8, &code) == 8 &&
+            (!strcmp(kind, "gemm") || !strcmp(kind, "conv")) && code > 0) {
+            k.mode = kind[0] == 'c';
+            ctx->tuned[k] = code;
+            ++n;
+        }
+        const char* nl = strchr(q, '\n');
+        if (!nl) break;
+        q = nl + 1;
+    }
+    return n;
+}
+
 int fie_debug_gemm_stamps(fie_ctx* ctx, void* buf) {
     FIE_REQUIRE(ctx != nullptr, "fie_debug_gemm_stamps: NULL ctx");
     ctx->gemm_stamps = static_cast<unsigned*>(buf);

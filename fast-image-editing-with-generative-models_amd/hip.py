@@ -106,6 +106,7 @@ SIGNATURES = {
     "fie_groupnorm_stats_nhwc_f16": [_P, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _P, _I],
     "fie_gemm_autotune": [_P, _I],
     "fie_gemm_autotune_report": [_P, ctypes.c_char_p, _I],
+    "fie_gemm_autotune_load": [_P, ctypes.c_char_p],
     "fie_debug_tune_exclude": [_P, ctypes.c_char_p],
     "fie_debug_gemm_probe": [_P, _I],
     "fie_debug_epilogue_prefetch": [_P, _I],
@@ -201,6 +202,8 @@ class Program:
         return lib().fie_program_launches(self.h)
 
     def run(self):
+        """Re-issues the launches on torch's current stream.  Ordered against the program's own previous pass by the library (include/fie.h,
+        ORDERING CONTRACT); the producers of the static inputs are the caller's to order (`stream.wait_stream(...)`)."""
         self.ctx.sync_stream()
         _chk(lib().fie_program_run(self.ctx.h, self.h))
         return self.outputs
@@ -254,6 +257,9 @@ class Context:
         self._gn_gen = 0
         self._sk_ws = {}               # split-K workspaces (fie_splitk_workspace), one per (stream, graph slot)
         self._sk_bound = None
+        self._sk_pinned = False        # True while a program records: the program's OWN workspace stays bound (record())
+        self._cap_stream = None
+        self._prog_ws = []             # weak references to the live programs' workspaces (splitk_counters_clear)
         self.splitk_bytes = int(os.environ.get("FIE_SPLITK_MB", "96")) << 20      # 0: never split K
         self.gn_from_epilogue = os.environ.get("FIE_GN_FROM_EPILOGUE", "1") != "0"
         self.gn_quads = os.environ.get("FIE_GN_QUADS", "1") != "0"      # ... also for the UNet's 20 / 40-channel groups (quad partials); A/B switch
@@ -267,6 +273,12 @@ class Context:
         # fp8 ACTIVATIONS for the transformer-block projections of an fp8-weight model (csrc/gemm_x8.hip): the producers (LayerNorm, attention,
         # the GEGLU epilogue) write e4m3 and the GEMMs run the block-scaled MFMA.  FIE_A8=0 keeps fp16 activations (round-2 behaviour: A/B)
         self.a8 = os.environ.get("FIE_A8", "1") != "0"
+        # Tile / split-K choices from a file (include/fie.h: fie_gemm_autotune_load): FIE_TUNE_TABLE=<report of an earlier process>.  With
+        # FIE_TUNE_FROZEN=1 the pipelines never time anything new (shapes outside the table use the built-in rule): one choice per shape on
+        # every box, which is what the test session pins (tests/conftest.py); direct ctx.autotune(1) calls still tune live.
+        self.tune_frozen = os.environ.get("FIE_TUNE_FROZEN", "0") == "1"
+        self.tune_table_entries = 0
+        self.load_tune_table()
 
     def fetch_device_errors(self):
         """Queues the 16-byte D2H copy of the error word on the current stream (call before a synchronisation that happens anyway)."""
@@ -291,19 +303,52 @@ class Context:
             _chk(lib().fie_ctx_set_stream(self.h, s))
             self._stream = s
 
+    def load_tune_table(self, path=None):
+        """Remembered tile / split-K choices from the text of an autotune report (FIE_TUNE_TABLE by default).  Returns the number loaded."""
+        path = path or os.environ.get("FIE_TUNE_TABLE")
+        if not path or self.f32:
+            return 0
+        with open(path) as f:
+            n = lib().fie_gemm_autotune_load(self.h, f.read().encode())
+        if n < 0:
+            raise FieError(f"fie_gemm_autotune_load: {lib().fie_last_error().decode()}")
+        self.tune_table_entries = n
+        return n
+
     def _bind_splitk(self):
         """Split-K launches that may run concurrently must not share arrival counters / slabs: every (stream, graph slot) owns a
-        workspace (zeroed once: the kernels leave the counters zero), bound to the C context before a GEMM / conv is issued there."""
+        workspace (zeroed once: the kernels leave the counters zero), bound to the C context before a GEMM / conv or a C++ graph walk is
+        issued there.  While a program records, the program's own workspace stays bound instead (record())."""
+        if self._sk_pinned or self.f32 or not self.splitk_bytes:
+            return
         key = (self._stream, self.ws_tag)
-        if key == self._sk_bound or self.f32 or not self.splitk_bytes:
+        if key == self._sk_bound:
             return
         ws = self._sk_ws.get(key)
         if ws is None:
+            # under stream capture torch.zeros would become a 96 MB memset node replayed with the graph: callers that capture bind the capture
+            # stream's workspace BEFORE entering the capture (pipe._capture); a key first met inside a capture keeps working, only slower
             ws = self._sk_ws[key] = torch.zeros(self.splitk_bytes, device=self.device, dtype=torch.uint8)
-        if self._keep is not None:
-            self._keep.append(ws)
         _chk(lib().fie_splitk_workspace(self.h, ws.data_ptr(), ws.numel()))
         self._sk_bound = key
+
+    def capture_stream(self):
+        """The stream this context's hipGraph captures run on (`torch.cuda.graph(g, stream=ctx.capture_stream())`), with the split-K workspace
+        of (that stream, current ws_tag) bound BEFORE the capture begins: allocated inside a capture, its torch.zeros would be a 96 MB memset
+        node that every replay re-runs."""
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._cap_stream):
+            self.sync_stream()
+            self._bind_splitk()
+        torch.cuda.synchronize(self.device)
+        return self._cap_stream
+
+    def splitk_counters_clear(self):
+        """True when every arrival counter of every split-K workspace of this context is zero (synchronises): what each launch must leave."""
+        torch.cuda.synchronize(self.device)
+        live = list(self._sk_ws.values()) + [w for w in (r() for r in self._prog_ws) if w is not None]
+        return all(int(ws[:16384].view(torch.int32).abs().max()) == 0 for ws in live)
 
     # ------------------------------------------------------------------ launch programs / graph-level entries
     def record(self):
@@ -316,6 +361,16 @@ class Context:
         def cm():
             prog = Program(self)
             self.sync_stream()
+            # the program OWNS its split-K workspace (include/fie.h, ORDERING CONTRACT (2)): the recorded launches freeze its pointer, and no
+            # stream's eager launches or other program ever share its arrival counters / slabs
+            own = None
+            if not self.f32 and self.splitk_bytes:
+                own = torch.zeros(self.splitk_bytes, device=self.device, dtype=torch.uint8)
+                prog.keep.append(own)
+                import weakref
+                self._prog_ws = [r for r in self._prog_ws if r() is not None] + [weakref.ref(own)]
+                _chk(lib().fie_splitk_workspace(self.h, own.data_ptr(), own.numel()))
+                self._sk_pinned = True
             _chk(lib().fie_program_begin(self.h, ctypes.byref(prog.h)))
             self._keep = prog.keep
             try:
@@ -323,6 +378,9 @@ class Context:
             finally:
                 self._keep = None
                 _chk(lib().fie_program_end(self.h))
+                if own is not None:
+                    self._sk_pinned = False
+                    self._sk_bound = None           # the next GEMM / conv re-binds its stream's workspace
         return cm()
 
     def run_named(self, name):
@@ -354,7 +412,7 @@ class Context:
         return lib().fie_debug_tune_exclude(self.h, (codes or "").encode())
 
     def autotune_report(self):
-        buf = ctypes.create_string_buffer(1 << 16)
+        buf = ctypes.create_string_buffer(1 << 20)
         n = lib().fie_gemm_autotune_report(self.h, buf, len(buf))
         return n, buf.value.decode()
 

@@ -280,11 +280,16 @@ class HipImg2ImgPipeline:
         the same job then use the same kernels.  That matters since round 3: a split-K choice changes the fp32 summation order, so
         unlike the tile choice it can move the last bit of an f16 output (eager == replay is asserted bit for bit by the tests)."""
         with self.eager_lock:
-            self.ctx.autotune(1 if self.autotune else 0)
+            self.ctx.autotune(self._tune_mode())
             try:
                 return self.run_device(job)
             finally:
                 self.ctx.autotune(2 if self.autotune else 0)
+
+    def _tune_mode(self):
+        """fie_gemm_autotune mode of a pass that may meet new shapes: 1 (time them), or 2 (remembered choices only) when the context's choices
+        are frozen to a loaded table (FIE_TUNE_TABLE + FIE_TUNE_FROZEN=1: the test session), 0 with FIE_AUTOTUNE=0."""
+        return 0 if not self.autotune else 2 if self.ctx.tune_frozen else 1
 
     MAX_FORKED_GRAPHS = 6
 
@@ -344,7 +349,7 @@ class HipImg2ImgPipeline:
         static["t_dev"] = [t.clone() for t in job["t_dev"]]
         timing, self.timing = self.timing, None
         self.ctx.ws_tag = slot
-        self.ctx.autotune(1 if self.autotune else 0)
+        self.ctx.autotune(self._tune_mode())
         self.run_device(static)                     # eager warm-up: lazy workspaces / function attributes, tile autotune
         torch.cuda.synchronize()
         self.ctx.autotune(2 if self.autotune else 0)   # frees the tuner's scratch; the capture below uses what it remembered
@@ -352,8 +357,12 @@ class HipImg2ImgPipeline:
         pool = self._pools.get(slot)
         if pool is None:
             pool = self._pools[slot] = torch.cuda.graph_pool_handle()
+        # The capture stream is ours (created here, where torch would create its default one: same first-use order of streams) so that
+        # its split-K workspace can be bound BEFORE the capture: allocated inside, its torch.zeros became a 96 MB memset node that every
+        # replay of the slot's first graph re-ran
+        cap = self.ctx.capture_stream()
         # thread_local: other worker threads keep replaying / allocating on their own streams during this capture
-        with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
+        with torch.cuda.graph(graph, pool=pool, stream=cap, capture_error_mode="thread_local"):
             out = self.run_device(static)
         self.ctx.ws_tag = 0
         self.timing = timing

@@ -62,6 +62,17 @@ int fie_ctx_destroy(fie_ctx* ctx);
  * fie_program_run re-issues the whole list on the ctx stream from C++: no host-side shape logic, no Python, asynchronous and
  * hipGraph-capturable like any single op.  New inputs = new CONTENTS of the same input buffers.  The caller keeps every buffer
  * the program references alive and destroys programs it created.
+ * ORDERING CONTRACT (round 4).  A program's launches carry FROZEN pointers: its static buffers and the split-K workspace
+ * (fie_splitk_workspace) that was bound to the ctx while it was recorded -- arrival counters and partial-tile slabs included.  Therefore
+ *   (1) a program must never be in flight twice.  fie_program_run enforces this for eager runs: the recording pass and every run record
+ *       an event, and a run on a DIFFERENT stream than the previous pass first makes that stream wait for it (same stream: stream order).
+ *       Under stream capture nothing is ordered by the library: a captured graph that contains the program inherits the rule (do not
+ *       replay it while another copy of the program, captured or eager, is running);
+ *   (2) nothing else may use that split-K workspace concurrently: record a program with a workspace of its OWN bound
+ *       (fie_amd/hip.py: Context.record() allocates one per program and restores the previous binding afterwards);
+ *   (3) the buffers' producers are the caller's to order: make the run's stream wait for whatever wrote the inputs.
+ * A caller that breaks (1) / (2) gets undefined sums from the overlapping launches, but no lasting damage: the arrival counters are
+ * self-healing (every S-th arrival takes S off the counter; csrc/gemm_common.h: splitk_reduce).
  * What the five NAMED entries (fie_unet_forward ...) are NOT: a C++ implementation of the model graphs.  They are REPLAY HANDLES for a launch list
  * a host walk recorded, with every pointer frozen in.  The C++ implementations are the *_f16 forwards below (round 3).  The product path
  * (hipGraph replay of the Python walk, which takes more fusions) goes through neither; tests/test_programs_gpu.py covers both.
@@ -78,6 +89,8 @@ int fie_ctx_destroy(fie_ctx* ctx);
  *     likewise); "post_quant_conv.{weight,bias}" zero-padded to the 8-channel latent layout; CLIP: "zero_row" = `hidden` zeros.
  *   Workspaces: ONE caller-provided device buffer per call, >= the matching *_workspace_bytes(cfg) (the walk's allocation sequence replayed
  *     without launching: exact).  Asynchronous on the ctx stream, hipGraph-capturable, no allocation, no synchronisation.
+ *     The walks' GEMMs / convs split K where the tuner chose so, on the split-K workspace currently bound to the ctx (fie_splitk_workspace):
+ *     bind the workspace of the stream you are about to issue on BEFORE calling a forward (fie_amd/cabi.py does, per (stream, slot)).
  *   Same kernels and order as the Python walks (fie_amd/{clip,vae,nn}.py) apart from fusions those take and these do not (GroupNorm sums from the
  *     producing epilogue, 2x2-parity up-samplers, conv2 + shortcut as one GEMM, the one-launch timestep embedding, zero convs adding into the UNet's
  *     skips): results agree to rounding (tests/test_programs_gpu.py: <= 3e-3 of the output's max against the Python walk at full size).
@@ -153,7 +166,7 @@ typedef struct fie_program fie_program;
 int fie_program_begin(fie_ctx* ctx, fie_program** out);
 int fie_program_end(fie_ctx* ctx);
 int fie_program_launches(const fie_program* p);             /* number of recorded launches (-1: NULL) */
-int fie_program_run(fie_ctx* ctx, const fie_program* p);
+int fie_program_run(fie_ctx* ctx, fie_program* p);          /* see ORDERING CONTRACT above */
 int fie_program_destroy(fie_ctx* ctx, fie_program* p);      /* also drops its name bindings on ctx (ctx may be NULL) */
 int fie_graph_register(fie_ctx* ctx, const char* name, fie_program* p);
 int fie_unet_forward(fie_ctx* ctx);
@@ -398,13 +411,20 @@ int fie_prefetch(fie_ctx* ctx, const void* ptr, int64_t bytes, void* stream, int
 /* Split-K for the GEMM / conv ring kernels (M = 2048-class problems whose big tiles leave most CUs idle): binds a caller-owned device
  * workspace to the context -- 16 KiB of arrival counters that MUST be zero when bound (every launch leaves them zero again) followed by
  * the fp32 partial-tile slabs.  Launches that run concurrently (different streams) need different workspaces: bind the stream's own
- * before issuing on it.  NULL unbinds (no launch splits K then).  A launch splits only where the autotuner measured it faster, or an
+ * before issuing on it -- that holds for the op entries, for the *_forward_f16 walks and for recorded programs / captured graphs, which
+ * keep the workspace that was bound when they were recorded (see ORDERING CONTRACT at fie_program_run).  NULL unbinds (no launch splits
+ * K then).  The counters are self-healing (a launch takes its arrivals off again with one atomic subtract), so a violation of the rule
+ * corrupts only the overlapping launches' sums, never later ones.  A launch splits only where the autotuner measured it faster, or an
  * override asks (tile codes: split factor * 10000 + code); it falls back to the unsplit kernel when the workspace is too small.
  * Determinism: slices are summed in slice order by the block that arrives last, so results do not depend on timing. */
 int fie_splitk_workspace(fie_ctx* ctx, void* workspace, int64_t bytes);
 int fie_debug_splitk(fie_ctx* ctx, int mode);                       /* 0 = never split K, 1 = default */
 int fie_gemm_autotune(fie_ctx* ctx, int on);
 int fie_gemm_autotune_report(fie_ctx* ctx, char* buf, int cap);
+/* Remembered choices from a report's text (the inverse of fie_gemm_autotune_report; unknown lines are skipped): a host saves the report of a
+ * tuned process and loads it into the next one -- no timing launches at start-up and the same kernels on every box (a split-K choice moves
+ * the last f16 bit).  FIE_TUNE_TABLE=<file> makes fie_amd load it into every context.  Returns the number of problems loaded. */
+int fie_gemm_autotune_load(fie_ctx* ctx, const char* text);
 int fie_debug_tune_exclude(fie_ctx* ctx, const char* codes);        /* A/B hook (tools/tuner_ab.py): comma-separated tile codes the tuner must not offer (10000 = every split-K variant; NULL / "" = none); forgets every remembered choice; returns the number of codes parsed */
 int fie_debug_gemm_probe(fie_ctx* ctx, int mode);                  /* TIMING-ONLY probes of the LDS-DMA kernels (outputs are wrong): 0 off, 1 = DMA loads dropped by the descriptor, 2 = every tile loads tile (0,0), 3 = ring kernels: no DMA issued in the K loop, 4 = no epilogue */
 int fie_debug_epilogue_prefetch(fie_ctx* ctx, int on);            /* A/B switch (default on): the ring GEMM / conv kernels load the bias row and the residual tile BEFORE the K loop; results are identical either way */

@@ -7,9 +7,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# One tile / split-K choice per shape on EVERY box: the session loads the committed table of remembered
+# choices and the pipelines never time anything new (shapes outside the table run the built-in rule).  A split-K choice moves the last f16
+# bit, and a dozen tests assert bit equality between eager, recorded and replayed passes; which tile a fresh box happens to time fastest
+# must not decide which code paths the suite exercises.  The live tuner keeps its own tests (test_ops_gpu.py::test_gemm_autotune_*,
+# test_pipeline_gpu.py::test_live_tuner_*), which restore the table afterwards.  FIE_TUNE_LIVE=1 runs the whole session on the live tuner
+# (how tests/golden/tune_table.txt is regenerated: FIE_TUNE_LIVE=1 FIE_TUNE_DUMP=gpurun_out/tune_table.txt pytest -m gpu).
+TUNE_TABLE = os.path.join(ROOT, "tests", "golden", "tune_table.txt")
+if os.environ.get("FIE_TUNE_LIVE") != "1" and os.path.exists(TUNE_TABLE):
+    os.environ.setdefault("FIE_TUNE_TABLE", TUNE_TABLE)
+    os.environ.setdefault("FIE_TUNE_FROZEN", "1")
+
+# Oracle-parity tests first, self-comparison tests (eager == replay, program == eager) last: with `pytest -x` one red self-comparison
+# test must not hide the oracle tests behind it (GPUTEST r03: 11 tests of test_realwidth_gpu.py never ran).
+_ORDER = ["test_fullsize_gpu", "test_realwidth_gpu", "test_sdxl_gpu", "test_pipeline_gpu", "test_fp32_gpu", "test_fp8_gpu", "test_ops_gpu",
+          "test_cabi_graphs_gpu", "test_programs_gpu"]
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(mod) if mod in _ORDER else len(_ORDER)
+    items.sort(key=rank)                                  # stable: file order within a module stays
 
 
 @pytest.fixture(scope="session")
@@ -17,4 +40,11 @@ def fie():
     """The product's HIP context; raises (never falls back) when the library or the GPU is missing."""
     import fie_amd  # noqa: F401
     from fie_amd import hip
-    return hip.context(0)
+    ctx = hip.context(0)
+    yield ctx
+    dump = os.environ.get("FIE_TUNE_DUMP")
+    if dump:                                              # the session's remembered choices, in the format fie_gemm_autotune_load reads
+        n, text = ctx.autotune_report()
+        os.makedirs(os.path.dirname(os.path.abspath(dump)), exist_ok=True)
+        with open(dump, "w") as f:
+            f.write(f"# {n} problems; fie_gemm_autotune_report of one `pytest -m gpu` session on the live tuner (MI355X)\n" + text)

@@ -49,6 +49,7 @@ def test_vae_decode_and_encode_walked_in_cpp(fie, stack_name, lat):
         assert _rel(out[0, ..., :3].permute(2, 0, 1).cpu(), oref[0]) < 2e-2
         # capturable: the whole C++ walk inside a hipGraph, replayed on new latents
         s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())      # zd and the walks above were issued on the default stream: order the side stream behind them
         with torch.cuda.stream(s):
             static_z = zd.clone()
             cabi.vae_decode(vae, static_z)
@@ -175,6 +176,7 @@ def test_controlnet_and_unet_walked_in_cpp(fie, stack_name, lat):
         assert max(_rel(d.permute(0, 3, 1, 2).cpu(), r) for d, r in zip(downs + [midr], od + [om])) < 2e-2
         # capturable, deterministic
         s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())      # the inputs and eps0 were produced on the default stream
         with torch.cuda.stream(s):
             cabi.unet_forward(unet, "unet.", x, t, text, pooled, tid)
             torch.cuda.synchronize()

@@ -156,11 +156,12 @@ def full(fie):
     return cfgs, sds32, pipe
 
 
-def test_full_size_unet_controlnet_eval_vs_oracle(full, fie):
-    """One ControlNet + UNet evaluation at 128x128 latents / a 1024x1024 edge map, batch 1, t = 499, conditioning scale 0.5."""
+def eval_vs_oracle(cfgs, sds32, pipe, fie, seed=5, t=499):
+    """One ControlNet + UNet evaluation at 128x128 latents / a 1024x1024 edge map, batch 1, conditioning scale 0.5: `pipe` (HIP) against
+    oracle/nets.py on the fp32 state dicts `sds32`.  Returns (eps error, worst error of the ten ControlNet residuals), each max-abs relative to
+    the oracle tensor's max-abs.  Shared with tests/test_sdxl_gpu.py (the SDXL-base stack, fp16 and fp8)."""
     from oracle import nets
-    cfgs, sds32, pipe = full
-    g = torch.Generator().manual_seed(5)
+    g = torch.Generator().manual_seed(seed)
     lh = lw = 128
     lat = torch.randn(1, 4, lh, lw, generator=g).half().float()
     cond = (torch.rand(1, 3, lh * 8, lw * 8, generator=g) > 0.9).float()
@@ -168,7 +169,6 @@ def test_full_size_unet_controlnet_eval_vs_oracle(full, fie):
     text = torch.randn(1, 77, xd, generator=g).half().float()
     pooled = torch.randn(1, 1280, generator=g).half().float()
     tid = torch.tensor([[1024., 1024., 0, 0, 1024., 1024.]])
-    t = 499
     with torch.no_grad():
         down, mid = nets.controlnet_forward(sds32["controlnet"], cfgs["controlnet"], lat, t, text, cond, 0.5, pooled, tid)
         ref = nets.unet_forward(sds32["unet"], cfgs["unet"], lat, t, text, pooled, tid, down, mid)
@@ -191,7 +191,13 @@ def test_full_size_unet_controlnet_eval_vs_oracle(full, fie):
     worst = max(rel_err(a.permute(0, 3, 1, 2), b) for a, b in zip(r_skips + [r_mid], list(down) + [mid]))
     skips2, m2 = pipe.controlnet.add_residuals(c_skips, c_mid, 0.5, skips, m)
     eps = pipe.unet.decode(m2, skips2, tb_u, text_d, 77)
-    e = rel_err(eps.permute(0, 3, 1, 2), ref)
+    return rel_err(eps.permute(0, 3, 1, 2), ref), worst
+
+
+def test_full_size_unet_controlnet_eval_vs_oracle(full, fie):
+    """One ControlNet + UNet evaluation at 128x128 latents / a 1024x1024 edge map, batch 1, t = 499, conditioning scale 0.5."""
+    cfgs, sds32, pipe = full
+    e, worst = eval_vs_oracle(cfgs, sds32, pipe, fie)
     print(f"full-size eval vs oracle: eps rel_err={e:.2e}, worst ControlNet residual rel_err={worst:.2e}")
     assert worst < 2e-2 and e < 2e-2
 

@@ -524,7 +524,10 @@ def test_gemm_autotune_picks_by_measurement_and_keeps_results(fie):
     ref_res = fie.gemm(ad, wp, n, bias=bd, residual=res0, out=res0.clone()).clone()
     ref_conv = fie.conv3x3(x, wc, 192).clone()
     rule_kernel = hip.last_gemm_kernel(fie)
+    remembered = fie.autotune_report()[1]               # the session's choices (the pinned table, or what a live session tuned so far): restored below
+    fie.tune_exclude("")                                # this test starts from an empty memory, whatever the table holds
     n0 = fie.autotune_report()[0]
+    assert n0 == 0
     try:
         fie.splitk(False)                               # split-K changes the fp32 summation order: its own test below
         fie.autotune(1)
@@ -552,6 +555,8 @@ def test_gemm_autotune_picks_by_measurement_and_keeps_results(fie):
     finally:
         fie.autotune(0)
         fie.splitk(True)
+        fie.tune_exclude("")
+        assert hip.lib().fie_gemm_autotune_load(fie.h, remembered.encode()) == remembered.count(" -> ")
     fie.conv3x3(x, wc, 192)
     assert hip.last_gemm_kernel(fie) == rule_kernel
 
@@ -608,6 +613,25 @@ def test_split_k_in_launch_reduction(fie):
             assert torch.equal(got, first[(it + 1) % 2]) and torch.equal(other, first[it % 2]), it
         for ws in fie._sk_ws.values():
             assert int(ws[:16384].view(torch.int32).abs().sum()) == 0           # every launch leaves its arrival counters zero
+        # self-healing counters (round 4; GPUTEST r03's failure): two streams issue split launches on ONE workspace with no ordering -- a
+        # violation of the per-stream rule whose overlapping sums are undefined -- and afterwards every counter is zero again and the next
+        # (lawful) launches are exact.  With the old "== S - 1, store 0" ticket a counter stayed at 1 and corrupted every later launch.
+        fie.sync_stream()
+        fie._bind_splitk()
+        fie._sk_pinned = True                              # both streams keep the default stream's workspace
+        try:
+            for it in range(8):
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        fie.gemm(a1, wp, n, bias=bias)
+                for _ in range(4):
+                    fie.gemm(a0, wp, n, bias=bias)
+            torch.cuda.synchronize()
+        finally:
+            fie._sk_pinned = False
+            fie._sk_bound = None
+        assert fie.splitk_counters_clear()
+        assert torch.equal(fie.gemm(a0, wp, n, bias=bias), first[0]) and torch.equal(fie.gemm(a1, wp, n, bias=bias), first[1])
         # conv 3x3 + its 1x1 side inputs, 2x-upsampling parity conv, GroupNorm sums from the split epilogue
         x = rnd(2, 32, 32, 256, seed=31).to(DEV)
         wt = rnd(512, 256, 3, 3, seed=32, scale=(9 * 256) ** -0.5)

@@ -121,6 +121,7 @@ def test_program_inside_a_hipgraph(rig, fie):
         dec = pipe.vae.decode(z)
     ref = dec.clone()
     s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())          # z, dec and ref were produced on the default stream (include/fie.h, ORDERING CONTRACT (3))
     with torch.cuda.stream(s):
         pd.run()
         torch.cuda.synchronize()
@@ -131,4 +132,38 @@ def test_program_inside_a_hipgraph(rig, fie):
         graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(dec, ref)
+    assert fie.splitk_counters_clear(), "a split-K arrival counter was left non-zero"
     pd.close()
+
+
+def test_program_is_ordered_against_itself_across_streams(rig, fie):
+    """ORDERING CONTRACT (1) of include/fie.h: a program re-run on ANOTHER stream without any caller-side ordering still waits for its previous
+    pass (the library records an event behind every pass), and a program recorded with split-K launches owns its workspace, so eager split
+    GEMMs on the recording stream may run beside it.  Forced split-K (tile override) so that the hazard of GPUTEST r03 is really present:
+    unordered, two in-flight copies of one split launch interleave on one arrival counter."""
+    from fie_amd import hip
+    dev = fie.device
+    g = torch.Generator().manual_seed(11)
+    m, n, k = 256, 256, 4096
+    a = torch.randn(m, k, generator=g).half().to(dev)
+    w = fie.pack_linear((torch.randn(n, k, generator=g) * k ** -0.5).half())
+    fie.tile_override(f"0,{m},{n},{k}=30051")            # split-K 3 on the 128x128 ring tile: 4 tiles x 3 slices
+    prog = None
+    try:
+        with fie.record() as prog:
+            outs = [fie.gemm(a, w, n) for _ in range(8)]
+        assert "split-K 3" in hip.last_gemm_kernel(fie)
+        ref = [o.clone() for o in outs]
+        torch.cuda.synchronize()
+        side = [torch.cuda.Stream() for _ in range(3)]
+        for rep in range(6):                              # the same program hopping streams back to back, eager split GEMMs beside it
+            with torch.cuda.stream(side[rep % 3]):
+                prog.run()
+            eager = fie.gemm(a, w, n)                     # default stream: its own workspace, not the program's
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, r) for o, r in zip(outs, ref)) and torch.equal(eager, ref[0])
+        assert fie.splitk_counters_clear(), "a split-K arrival counter was left non-zero"
+    finally:
+        fie.tile_override(None)
+        if prog is not None:
+            prog.close()
