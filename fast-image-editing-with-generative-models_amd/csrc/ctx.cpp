@@ -9,6 +9,7 @@ int fie_gemm8_init(void);
 int fie_gemm_w8_init(void);
 int fie_attn_init(void);
 int fie_gemm_x8_init(void);
+int fie_conv_halo_init(void);
 
 static thread_local char g_err[512] = "";
 
@@ -91,6 +92,7 @@ int fie_ctx_create(int device, void* stream, fie_ctx** out) {
     if (rc == FIE_OK) rc = fie_gemm_w8_init();
     if (rc == FIE_OK) rc = fie_attn_init();
     if (rc == FIE_OK) rc = fie_gemm_x8_init();
+    if (rc == FIE_OK) rc = fie_conv_halo_init();
     (void)hipSetDevice(cur);
     if (rc != FIE_OK) return rc;
     fie_ctx* c = new fie_ctx();

@@ -522,6 +522,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 int fie_launch_gemm8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int conv, int split);
 int fie_gemm8_init(void);          // per-device function attributes (dynamic LDS size); called from fie_ctx_create
 int fie_gemm_init(void);           // same for the kernels of gemm_conv.hip
+// conv_halo.hip: the halo-resident 3x3 conv (tile code 71; 73 = with cycle stamps): a block = a 16x16 output patch x 128 channels
+int fie_launch_conv_halo(fie_ctx* ctx, fie_gemm::GemmArgs& a, int stamped);
+bool fie_conv_halo_ok(const fie_gemm::GemmArgs& a);
+int fie_conv_halo_init(void);
 // gemm_w8.hip: fp8-weight ring kernels; code 62 = 256x128 (8 waves), 42 = 128x64, 43 = 64x64
 int fie_launch_gemm_w8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int conv, int code);
 int fie_gemm_w8_init(void);

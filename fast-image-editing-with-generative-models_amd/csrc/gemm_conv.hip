@@ -563,11 +563,15 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
 //   95 / 96        gemm3_kernel 51 / 62 with fragment reads one half K-step ahead of the MFMAs (the 4-wave and 2-stage tiles gain nothing from it)
 //   97 / 98 / 94   62 / 96 / 42 with in-kernel cycle stamps (fie_debug_gemm_stamps; slower, for tools/kstep_stamps.py only)
 //   81 / 82        gemm8_kernel  256x256 phased (82: second DMA piece of each phase inside the MFMA cluster, A/B: slower)
+//   71 / 73        conv_halo_kernel (conv_halo.hip): a 16x16 output patch x 128 channels per block, the patch's 18x18 halo resident in LDS per
+//                  64-channel chunk, weights through a ring; stride-1 same-size convs with H, W % 16 == 0 only (73: with cycle stamps).
+//                  K is summed chunk-major (the im2col kernels: tap-major): equal to the other codes to rounding, not bit for bit
 struct TileDim { int code, bm, bn; };
 constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {42, 128, 64}, {43, 64, 64},
                               {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256},
                               {63, 256, 320}, {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
-                              {52, 128, 128}, {47, 128, 96}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}, {48, 128, 80}, {64, 256, 320}};
+                              {52, 128, 128}, {47, 128, 96}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}, {48, 128, 80}, {64, 256, 320},
+                              {71, 256, 128}, {73, 256, 128}};
 
 // Heuristic tile code for a shape (the default; the autotuner below and the debug hooks can replace it).
 template <int MODE>
@@ -628,6 +632,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     FIE_REQUIRE(code < 40 || dma_ok, "tile code %d: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)", code);
     FIE_REQUIRE(!(a.taps2 && (code < 40 || a.w_scale)), "tile code %d: the 2x2 parity convs run on the f16 LDS-DMA kernels only", code);
     FIE_REQUIRE(!(MODE == 1 && a.A2 && (code < 40 || code == 81 || code == 82 || a.w_scale)), "tile code %d: conv + 1x1 side inputs run on the f16 ring kernels only", code);
+    FIE_REQUIRE(!((code == 71 || code == 73) && (MODE != 1 || !dma_ok || !fie_conv_halo_ok(a))), "tile code %d (halo-resident conv): stride-1 same-size 3x3 conv with H, W %% 16 == 0, Cin %% 64 == 0, f16 weights only", code);
     if (order < 0) {
         // Tile order = which operand an XCD re-streams past its 4 MiB L2.  Consecutive tile ids run on one XCD (xcd_remap), so an
         // XCD owns T/8 consecutive tiles: with n fastest that is `dm` row blocks x up to all column tiles, with m fastest the
@@ -667,8 +672,8 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     a.order = order;
     a.probe = ctx->gemm_probe;
     a.epi_prefetch = ctx->epi_prefetch;
-    a.stamps = (code == 97 || code == 98 || code == 94) ? ctx->gemm_stamps : nullptr;
-    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 90 ? "gemm3_kernel+prefetch" : code >= 80 ? "gemm8_kernel" : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
+    a.stamps = (code == 97 || code == 98 || code == 94 || code == 73) ? ctx->gemm_stamps : nullptr;
+    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 90 ? "gemm3_kernel+prefetch" : code >= 80 ? "gemm8_kernel" : code == 71 || code == 73 ? "conv_halo_kernel" : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
              t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
     if (split > 1) snprintf(ctx->last_kernel + strlen(ctx->last_kernel) - 1, 24, ", split-K %d)", split);
     if (MODE == 1)
@@ -715,6 +720,8 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
         case 97: launch_ring<256, 128, 3, M3, 8, false, true>(ctx, a, grid); break;
         case 98: launch_ring<256, 128, 3, M3, 8, true, true>(ctx, a, grid); break;
         case 94: launch_ring<128, 64, 3, M3, 4, false, true>(ctx, a, grid); break;
+        case 71: return fie_launch_conv_halo(ctx, a, 0);
+        case 73: return fie_launch_conv_halo(ctx, a, 1);
         case 81: return fie_launch_gemm8(ctx, a, MODE == 1, 0);
         case 82: return fie_launch_gemm8(ctx, a, MODE == 1, 1);   // A/B: second DMA piece of a phase issued from inside the MFMA cluster (measured slower)
     }
