@@ -225,11 +225,424 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// v2 (tile code 72): the same K loop in a PERSISTENT block with DEFERRED STORES.  Stamps on v1 (profiles/r04_halo_conv_v1_first_run.log): of a
+// 1024^2 x 128 -> 128 tile's ~37 k cycles the K loop takes 24 k; the prologue (a cold 41 KB halo + 32 KB of weights: latency) 4.4-5.7 k and the
+// epilogue 7.4-9.6 k -- sixteen 8-byte-per-lane store instructions per wave that every CU issues at the same moment (blocks run in step), store-issue
+// bound (MI355X_MICROARCH.md, cycle constants: "attention epilogue store tail").  Here a block walks tiles bid, bid + G, bid + 2 G, ... and
+//   * the LAST chunk of a tile prefetches the NEXT tile's first halo (its six piece slots) and first two weight stages (9 K-steps per chunk and
+//     three stages: the ring position carries over), so the next K loop starts without a prologue;
+//   * at the end of a tile the accumulators get bias / row bias / activation / residual, the GroupNorm sums are written, and the results are
+//     packed to f16 into 32 registers; the sixteen stores are then issued TWO PER K-STEP in the load segments of the next tile's first chunk
+//     (taps 0..7), where they ride on the counted waits like any DMA piece: no wave ever waits for a store, and the chip's write traffic is
+//     spread over the K loop instead of coming in bursts;
+//   * RES: the residual tile (the resnet's identity shortcut, upstream resnet.py: output = conv2(h) + input) is loaded sixteen 8-byte pieces per
+//     lane in taps 2..7 of the tile's LAST chunk, i.e. while the deferred outputs' registers are free again (they are stored during the first
+//     chunk; Cin >= 128: the first chunk is never the last).
+// Every vector-memory instruction between two counted waits is issued unconditionally (out-of-range lanes and absent operands go through the
+// descriptors' range check), so the vmcnt immediates stay compile-time constants per (chunk kind, tap); after the one irregular event (the row
+// bias of another image) the wave drains completely, which is always safe.
+// The column tile of a block is fixed (the grid is a multiple of the column tiles): one weight stream and one bias vector per block.
+constexpr int K_FIRST = 0, K_MID = 1, K_LAST_F = 2, K_LAST_N = 3;      // chunk kinds: first (stores), middle, last with / without a next tile to prefetch
+constexpr int n2_w(int kind, int t) { return kind == K_LAST_N && t + 2 > 8 ? 0 : RWH; }
+constexpr int n2_h(int kind, int t) { return kind != K_LAST_N && t < HSLOTS ? 1 : 0; }
+constexpr int n2_st(int kind, int t) { return kind == K_FIRST && t < 8 ? 2 : 0; }
+constexpr int rl_cnt(int t) { return t >= 2 && t <= 5 ? 3 : (t == 6 || t == 7) ? 2 : 0; }
+constexpr int rl_first(int t) { int n = 0; for (int u = 0; u < t; ++u) n += rl_cnt(u); return n; }
+constexpr int n2_rl(bool res, int kind, int t) { return res && kind >= K_LAST_F ? rl_cnt(t) : 0; }
+// LOADS (LDS-DMA pieces, residual loads) issued BEHIND the weights in tap t's load segment.  STORES are deliberately not counted: measured in round 4
+// (tools/halo_race.py), a store does not reliably keep its place in the vmcnt order relative to LDS-DMA loads -- stores whose lanes are (mostly)
+// dropped by the range check retire early, and a wait that counted them let a weight piece through unretired about once in 500 launches.  Counting
+// loads only is safe either way: stores that retire early are not in the count, stores that are still pending only make the wait stricter.
+constexpr int n2_tail(bool res, int kind, int t) { return n2_h(kind, t) + n2_rl(res, kind, t); }
+// vmcnt that retires the weights of K-step kt + 1 (issued first in tap t - 1's load segment; tap 8 of every kind issues no load behind its weights)
+constexpr int n2_wait(bool res, int kind, int t) { return (t > 0 ? n2_tail(res, kind, t - 1) : 0) + n2_w(kind, t) + n2_tail(res, kind, t); }
+static_assert(rl_first(8) == 16 && n2_tail(true, K_LAST_F, 8) == 0 && n2_tail(true, K_FIRST, 8) == 0 && n2_st(K_FIRST, 8) == 0, "sixteen residual loads; tap 8 carries nothing behind its weights");
+
+template <bool RES, bool GN, bool RB, bool KH1L, bool STAMP>
+__global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
+    constexpr int FM = 4, FN = 4, WN = 64;
+    extern __shared__ __attribute__((aligned(16))) half_t smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave & 3, wn = wave >> 2;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    const int G = (int)gridDim.x;                               // a multiple of p.nbn: tile % nbn is the same for all of a block's tiles
+    const int ntiles = p.nbm * p.nbn;
+    const int bid = xcd_remap(blockIdx.x, G);
+    const int n0 = (bid % p.nbn) * BNH;
+    const int ppr = p.OW >> 4, ppi = (p.OH >> 4) * ppr;
+    const int ncol = n0 + wn * WN + fq * 4;                     // this lane's first output channel
+
+    const int live = p.probe == 1 ? 0 : 1;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)p.a1_bytes * live, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, (int)p.w_bytes * live, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2), 0x00020000);
+
+    // ---- tile geometry: first output row, image, the patch's corner
+    auto geom = [&](int tile, int& m0, int& img, int& y0, int& x0) {
+        const int patch = tile / p.nbn;
+        const int b = patch / ppi, pr = patch - b * ppi;
+        const int py = pr / ppr, px = pr - py * ppr;
+        y0 = py << 4; x0 = px << 4;
+        m0 = (b * p.OH + y0) * p.OW + x0;
+        img = b;
+    };
+    // halo piece slot i of this wave = piece q = wave + 8 i (8 pixels x 128 B); lane = (pixel lane >> 3, chunk position lane & 7).  Per slot ONE
+    // packed register (hy << 8 | hx; hy = 255: no pixel); the offsets are recomputed from it at every use behind an opaque asm -- left to
+    // itself the compiler hoists two dozen loop-invariant partial results per lane out of the tile loop and spills the deferred outputs instead
+    unsigned hq[HSLOTS];
+#pragma unroll
+    for (int i = 0; i < HSLOTS; ++i) {
+        const int q = wave + 8 * i;
+        const int pl = q * 8 + (lane >> 3);
+        const int hy = pl / HP, hx = pl - hy * HP;
+        hq[i] = q < HPIECES && pl < HP * HP ? (unsigned)((hy << 8) | hx) : 0xFF00u;
+    }
+    auto halo_off = [&](int i, int img, int y0, int x0) -> unsigned {
+        unsigned t = hq[i];
+        asm volatile("" : "+v"(t));
+        const int hy = (int)(t >> 8), hx = (int)(t & 255u);
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool ok = hy < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const unsigned chunk = (unsigned)((lane & 7) ^ (hx & 7));
+        return ok ? ((unsigned)(img * p.H + iy) * (unsigned)p.W + (unsigned)ix) * (unsigned)p.Cin * 2u + chunk * 16u : kOob;
+    };
+    auto halo_dst = [&](int i, int buf) -> half_t* {
+        const int q = wave + 8 * i;
+        return reinterpret_cast<half_t*>(lds + (q < HPIECES ? buf * HALO_B + q * 1024 : DUMP_OFF));
+    };
+    const int lr = lane >> 3;
+    const unsigned w_base = (unsigned)(n0 + wave * 8 + lr) * (unsigned)p.ldw * 2u + (unsigned)((lane & 7) ^ lr) * 16u;
+    const unsigned w_step = 64u * (unsigned)p.ldw * 2u;
+    auto issue_w = [&](int stage, unsigned soff) {
+#pragma unroll
+        for (int i = 0; i < RWH; ++i)
+            bload16(rs_w, reinterpret_cast<half_t*>(lds + WRING_OFF + stage * WSTAGE_B + (wave + 8 * i) * 1024), w_base + (unsigned)i * w_step, soff);
+    };
+    const unsigned cin2 = (unsigned)p.Cin * 2u;
+
+    unsigned a_rd[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+            a_rd[kx][kh] = (unsigned)((wm * FM * HP + fr + kx) * 128 + (((kh * 4 + fq) ^ ((fr + kx) & 7)) << 4));
+    unsigned w_rd[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) w_rd[kh] = (unsigned)(2 * lds_off(wn * WN + fr, kh * 4 + fq));
+
+    // bias of this lane's channels (zeros when absent): loaded once, a block keeps its column tile
+    u32x2 bv[FN], rbv[FN];
+    {
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.bias), 0, p.bias ? p.N * 2 : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            bv[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_b, (unsigned)(ncol + i * 16) * 2u, 0, 0);
+            rbv[i] = (u32x2){0u, 0u};
+        }
+    }
+    // byte offset of (first fragment row, this lane's first channel) in a [M, ld] matrix; fragment row j is j * OW * ld * 2 further
+    auto row_off = [&](int m0, int64_t ld) -> unsigned {
+        return ((unsigned)(m0 + wm * FM * p.OW + fr) * (unsigned)ld + (unsigned)ncol) * 2u;        // N % 128 == 0 (launcher): every wave's channels are inside the matrix
+    };
+    const unsigned c_jstep = (unsigned)p.OW * (unsigned)p.ldc * 2u, r_jstep = (unsigned)p.OW * (unsigned)p.ldr * 2u;
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ONE register array, two tenants with disjoint lifetimes: the previous tile's results (packed f16) from its tile end until their store slots in
+    // this tile's FIRST chunk; RES: this tile's residual values from their load slots in the LAST chunk (never the first: Cin >= 128) until the tile end
+    u32x2 outp[FN][FM];
+    unsigned ro_prev = 0, rr_cur = 0;
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) outp[i][j] = (u32x2){0u, 0u};
+
+    unsigned seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;     // STAMP: [0] DMA / store issue, [1] reads, [2] wait + barrier, [3] MFMA, [4] barrier, [5] prologue, [6] flush, [7] tile-end math
+    auto stamp = [&](int i) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+            seg[i] += t - tprev;
+            tprev = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (STAMP) tprev = (unsigned)__builtin_amdgcn_s_memtime();
+
+    const int nchunks = p.Cin / BK;                            // >= 2 (checked by the launcher)
+    int tile = bid, m0 = 0, img = 0, y0 = 0, x0 = 0, img_rb = -1;
+    geom(tile, m0, img, y0, x0);
+    unsigned h_off[HSLOTS];
+#pragma unroll
+    for (int i = 0; i < HSLOTS; ++i) h_off[i] = halo_off(i, img, y0, x0);
+    // the bias has landed before anything else is in flight (its registers are read at every tile end)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < FN; ++i) asm volatile("" : "+v"(bv[i]));
+
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(p.gn_partial, 0, GN && p.gn_partial ? (p.M / (p.OH * p.OW)) * (p.gn_nch ? p.gn_nch : p.gn_rows >> 5) * p.gn_G * 8 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.res), 0, RES && p.res ? (int)(((int64_t)(p.M - 1) * p.ldr + p.N) * 2) : 0, 0x00020000);
+
+    // ---- prologue: the first tile's first halo, the weights of its K-steps 0 and 1
+#pragma unroll
+    for (int i = 0; i < HSLOTS; ++i) bload16(rs_a, halo_dst(i, 0), h_off[i], 0u);
+    issue_w(0, 0u);
+    issue_w(1, cin2);
+    wait_vm_barrier<RWH>();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    stamp(5);
+
+    f16x8 fw[2][FN], fa[2][FM];
+    // NEXT = the tile whose first halo the last chunk prefetches (its geometry in imgn / y0n / x0n); other chunks prefetch this tile's chunk c + 1 from h_off
+    int imgn = 0, y0n = 0, x0n = 0;
+    auto kstep = [&](auto kindc, auto tapc, int c, unsigned hb, int hpf_buf) {
+        constexpr int KIND = decltype(kindc)::value;
+        constexpr int T = decltype(tapc)::value;
+        constexpr int KY = T / 3, KX = T % 3;
+        constexpr int STAGE = T % STH, FILL = (T + 2) % STH;
+        // ---- load segment: weights of K-step kt + 2, a halo piece, two deferred stores, residual loads (n2_wait counts the loads)
+        if constexpr (n2_w(KIND, T) > 0) {
+            constexpr int T2 = (T + 2) % 9;
+            const int c2 = T + 2 > 8 ? (KIND >= K_LAST_F ? 0 : c + 1) : c;
+            issue_w(FILL, (unsigned)T2 * cin2 + (unsigned)c2 * (BK * 2));
+        }
+        if constexpr (n2_h(KIND, T) > 0) {
+            if constexpr (KIND == K_LAST_F) bload16(rs_a, halo_dst(T, hpf_buf), halo_off(T, imgn, y0n, x0n), 0u);      // the next tile's first halo: offsets computed here (6 VGPRs saved)
+            else bload16(rs_a, halo_dst(T, hpf_buf), h_off[T], (unsigned)(c + 1) * (BK * 2));
+        }
+        if constexpr (n2_st(KIND, T) > 0) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                constexpr int K0 = 2 * T;
+                const int k = K0 + s, j = k / FN, i = k % FN;
+                __builtin_amdgcn_raw_buffer_store_b64(outp[i][j], rs_c, ro_prev + (unsigned)j * c_jstep + (unsigned)(i * 32), 0, 0);
+            }
+        }
+        if constexpr (n2_rl(RES, KIND, T) > 0) {
+#pragma unroll
+            for (int s = 0; s < rl_cnt(T); ++s) {
+                const int k = rl_first(T) + s, j = k / FN, i = k % FN;
+                outp[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, rr_cur + (unsigned)j * r_jstep + (unsigned)(i * 32), 0, 0);
+            }
+        }
+        stamp(0);
+        const char* const hal = lds + hb;
+        const char* const wst = lds + WRING_OFF + STAGE * WSTAGE_B;
+        auto reads = [&](int kh) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i) fw[kh][i] = *reinterpret_cast<const f16x8*>(wst + w_rd[kh] + i * 16 * 128);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) fa[kh][j] = *reinterpret_cast<const f16x8*>(hal + a_rd[KX][kh] + (j + KY) * HP * 128);
+        };
+        reads(0);
+        if constexpr (!KH1L) reads(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(1);
+        wait_vm_barrier<n2_wait(RES, KIND, T)>();
+        stamp(2);
+        // ---- MFMA segment (KH1L: the second k half's fragments are read here, under the first half's MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KH1L) { reads(1); __builtin_amdgcn_sched_barrier(0); }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kh][i], fa[kh][j], acc[i][j], 0, 0, 0);
+            if constexpr (KH1L) { if (kh == 0) __builtin_amdgcn_sched_barrier(0); }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(3);
+        __builtin_amdgcn_s_barrier();
+        stamp(4);
+    };
+    auto chunk = [&](auto kindc, int c, unsigned hb, int hpf_buf) {
+        kstep(kindc, std::integral_constant<int, 0>{}, c, hb, hpf_buf);
+        kstep(kindc, std::integral_constant<int, 1>{}, c, hb, hpf_buf);
+        kstep(kindc, std::integral_constant<int, 2>{}, c, hb, hpf_buf);
+        kstep(kindc, std::integral_constant<int, 3>{}, c, hb, hpf_buf);
+        kstep(kindc, std::integral_constant<int, 4>{}, c, hb, hpf_buf);
+        kstep(kindc, std::integral_constant<int, 5>{}, c, hb, hpf_buf);
+        kstep(kindc, std::integral_constant<int, 6>{}, c, hb, hpf_buf);
+        kstep(kindc, std::integral_constant<int, 7>{}, c, hb, hpf_buf);
+        kstep(kindc, std::integral_constant<int, 8>{}, c, hb, hpf_buf);
+    };
+
+    // ---- end of a tile: bias, row bias, activation, scale, residual on the accumulators (the order of gemm_common.h's epilogue); GroupNorm sums of
+    // the f16-rounded results; pack to f16; clear the accumulators
+    auto tile_end = [&](int m0c, int imgc) {
+        auto as_h4 = [](u32x2 v) { f16x4 h; __builtin_memcpy(&h, &v, 8); return h; };
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const f16x4 b = as_h4(bv[i]);
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)b[r];
+            if constexpr (RB) {
+                const f16x4 rb = as_h4(rbv[i]);
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)rb[r];
+            }
+        }
+        // (no activation / scale here: the launcher sends such convs -- the ControlNet's tiny conditioning embedding -- to v1)
+        if constexpr (RES) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) {
+                    const f16x4 r4 = as_h4(outp[i][j]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)r4[r];
+                }
+        }
+        if constexpr (GN) {
+            // as gemm_common.h's epilogue (one writer per (granule, group) slot), with the slot stores as unconditional buffer stores
+            const int ngrp = 16 / p.gn_cg;
+            const int gn_nch = p.gn_nch ? p.gn_nch : p.gn_rows >> 5;
+#pragma unroll
+            for (int jj = 0; jj < FM / 2; ++jj) {
+                const int mg = m0c + (wm * FM + 2 * jj) * p.OW;
+                const int rem = mg - imgc * p.gn_rows;
+                const int chunk = p.gn_chunk0 + ((rem / p.OW) >> 1) * (p.OW >> 4) + ((rem % p.OW) >> 4);
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    float sum = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x = (float)(half_t)acc[i][2 * jj + dj][r];
+                            sum += x;
+                            sq += x * x;
+                        }
+                    const float rs = row16_sum(sum), rq = row16_sum(sq);
+                    float ts[4], tq[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        ts[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs), 16 * k));
+                        tq[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rq), 16 * k));
+                    }
+                    if (p.gn_cg == 16) { ts[0] = (ts[0] + ts[1]) + (ts[2] + ts[3]); tq[0] = (tq[0] + tq[1]) + (tq[2] + tq[3]); }
+                    else if (p.gn_cg == 8) { ts[0] += ts[1]; tq[0] += tq[1]; ts[1] = ts[2] + ts[3]; tq[1] = tq[2] + tq[3]; }
+                    const int nfrag = n0 + wn * WN + i * 16;
+                    const float vs = lane == 0 ? ts[0] : lane == 1 ? ts[1] : lane == 2 ? ts[2] : ts[3];
+                    const float vq = lane == 0 ? tq[0] : lane == 1 ? tq[1] : lane == 2 ? tq[2] : tq[3];
+                    const bool ok = lane < ngrp && nfrag + lane * p.gn_cg < p.N;
+                    const unsigned off = ok ? (unsigned)(((imgc * gn_nch + chunk) * p.gn_G + nfrag / p.gn_cg + lane) * 8) : kOob;
+                    u32x2 bits;
+                    const float2 v2 = make_float2(vs, vq);
+                    __builtin_memcpy(&bits, &v2, 8);
+                    __builtin_amdgcn_raw_buffer_store_b64(bits, rs_g, off, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)acc[i][j][r];
+                __builtin_memcpy(&outp[i][j], &o, 8);
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+    };
+
+    int g = 0;                                                  // chunks run so far: halo buffer g & 1 is being read, (g + 1) & 1 being filled
+    bool first_tile = true;
+    for (;;) {
+        const int next = tile + G;
+        const bool have_next = next < ntiles;
+        int m0n = 0;
+        if (have_next) geom(next, m0n, imgn, y0n, x0n);
+        if constexpr (RB) {
+            if (img != img_rb) {                                // the row bias of another image: an irregular load, so drain everything (always safe)
+                const int nimg = p.M / (p.OH * p.OW);
+                const __amdgpu_buffer_rsrc_t rs_rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.rowbias), 0, p.rowbias ? (int)(((int64_t)(nimg - 1) * p.ld_rowbias + p.N) * 2) : 0, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < FN; ++i) rbv[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_rb, (unsigned)(img * (int)p.ld_rowbias + ncol + i * 16) * 2u, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < FN; ++i) asm volatile("" : "+v"(rbv[i]));
+                img_rb = img;
+            }
+        }
+        if constexpr (RES) rr_cur = row_off(m0, p.ldr);
+        // the block's first tile has nothing to store yet: its first chunk runs as a middle chunk.  (NOT as a first chunk with out-of-range dummy
+        // stores: a store whose lanes are all dropped by the range check does not keep its place in the vmcnt order -- the counted waits behind such
+        // dummies let DMA pieces through unretired, rarely and only on some variants: tools/halo_race.py, round 4.)
+        if (first_tile) chunk(std::integral_constant<int, K_MID>{}, 0, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
+        else chunk(std::integral_constant<int, K_FIRST>{}, 0, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
+        first_tile = false;
+        ++g;
+        for (int c = 1; c + 1 < nchunks; ++c, ++g) chunk(std::integral_constant<int, K_MID>{}, c, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
+        if (have_next) chunk(std::integral_constant<int, K_LAST_F>{}, nchunks - 1, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
+        else chunk(std::integral_constant<int, K_LAST_N>{}, nchunks - 1, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
+        ++g;
+        tile_end(m0, img);
+        ro_prev = row_off(m0, p.ldc);
+        stamp(7);
+        if (!have_next) break;
+        tile = next; m0 = m0n; img = imgn; y0 = y0n; x0 = x0n;
+#pragma unroll
+        for (int i = 0; i < HSLOTS; ++i) h_off[i] = halo_off(i, img, y0, x0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();                // pairs with group 1's last barrier
+    // ---- flush: the last tile's sixteen stores
+#pragma unroll
+    for (int j = 0; j < FM; ++j)
+#pragma unroll
+        for (int i = 0; i < FN; ++i) __builtin_amdgcn_raw_buffer_store_b64(outp[i][j], rs_c, ro_prev + (unsigned)j * c_jstep + (unsigned)(i * 32), 0, 0);
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(6);
+        if (p.stamps && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p.stamps[((size_t)bid * 8 + wave) * 8 + i] = seg[i];
+        }
+    }
+}
+
+template <bool RES, bool GN, bool RB, bool KH1L, bool STAMP>
+hipError_t halo2_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo2_kernel<RES, GN, RB, KH1L, STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo);
+}
+
 }  // namespace
 
 int fie_conv_halo_init(void) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo);
+    if (e == hipSuccess) e = halo2_attr<false, false, false, false, false>();
+    if (e == hipSuccess) e = halo2_attr<false, true, false, false, false>();
+    if (e == hipSuccess) e = halo2_attr<true, false, false, false, false>();
+    if (e == hipSuccess) e = halo2_attr<true, true, false, false, false>();
+    if (e == hipSuccess) e = halo2_attr<false, false, true, false, false>();
+    if (e == hipSuccess) e = halo2_attr<false, true, true, false, false>();
+    if (e == hipSuccess) e = halo2_attr<false, false, false, true, false>();
+    if (e == hipSuccess) e = halo2_attr<false, true, false, true, false>();
+    if (e == hipSuccess) e = halo2_attr<true, false, false, true, false>();
+    if (e == hipSuccess) e = halo2_attr<true, true, false, true, false>();
+    if (e == hipSuccess) e = halo2_attr<false, false, true, true, false>();
+    if (e == hipSuccess) e = halo2_attr<false, true, true, true, false>();
+    if (e == hipSuccess) e = halo2_attr<false, false, false, false, true>();
+    if (e == hipSuccess) e = halo2_attr<true, true, false, false, true>();
     if (e != hipSuccess) {
         fie_set_error("conv_halo: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return FIE_EHIP;
@@ -244,14 +657,47 @@ bool fie_conv_halo_ok(const GemmArgs& a) {
            a.OW % 16 == 0 && a.Cin % BK == 0 && a.Cin >= BK && !a.w_scale && a.K == 9 * a.Cin && !a.out_f8 && a.splitk <= 1;
 }
 
-int fie_launch_conv_halo(fie_ctx* ctx, GemmArgs& a, int stamped) {
-    FIE_REQUIRE(fie_conv_halo_ok(a), "tile code 71 (halo-resident conv): stride-1 same-size 3x3 conv with H, W %% 16 == 0 and Cin %% 64 == 0 only");
+// variant: 0 = v1 (one tile per block, code 71), 1 = v1 with stamps (73), 2 = v2 persistent + deferred stores (72), 3 = v2 with the second k half's
+// fragments read under the MFMAs (75), 4 = v2 with stamps (74)
+int fie_launch_conv_halo(fie_ctx* ctx, GemmArgs& a, int variant) {
+    FIE_REQUIRE(fie_conv_halo_ok(a), "halo-resident conv: stride-1 same-size 3x3 conv with H, W %% 16 == 0 and Cin %% 64 == 0 only");
     a.frag_ld = a.OW;
     a.nbn = (a.N + BNH - 1) / BNH;
     a.nbm = (a.M / (a.OH * a.OW)) * (a.OH >> 4) * (a.OW >> 4);
-    const dim3 grid((unsigned)(a.nbm * a.nbn));
-    if (stamped) fie_launch(ctx, (conv_halo_kernel<true>), grid, dim3(512), kLdsHalo, a);
-    else fie_launch(ctx, (conv_halo_kernel<false>), grid, dim3(512), kLdsHalo, a);
+    const int tiles = a.nbm * a.nbn;
+    // v2 stores during the first chunk and loads residuals in the last: two chunks at least; whole 128-channel column tiles (a wave whose channels lie
+    // past N would issue stores / loads that the range check drops whole, and those do not keep the vmcnt order the counted waits rely on); row bias and
+    // residual never come together (resnet conv1 / conv2); no activation / scale
+    if (variant >= 2 && (a.Cin < 2 * BK || a.N % BNH != 0 || (a.rowbias && a.res) || (variant == 4 && a.rowbias) || a.act != FIE_ACT_NONE || a.scale != 1.f)) variant = variant == 4 ? 1 : 0;
+    if (variant < 2) {
+        const dim3 grid((unsigned)tiles);
+        if (variant == 1) fie_launch(ctx, (conv_halo_kernel<true>), grid, dim3(512), kLdsHalo, a);
+        else fie_launch(ctx, (conv_halo_kernel<false>), grid, dim3(512), kLdsHalo, a);
+        FIE_LAUNCH_CHECK();
+        return FIE_OK;
+    }
+    // persistent grid: one block per CU (133 KB of LDS each), a multiple of the column tiles so that a block keeps its column tile
+    int g = tiles < ctx->num_cus ? tiles : ctx->num_cus;
+    g -= g % a.nbn;
+    FIE_REQUIRE(g >= a.nbn && a.nbn <= ctx->num_cus, "halo-resident conv: more column tiles than CUs");
+    const dim3 grid((unsigned)g);
+    const bool res = a.res != nullptr, gn = a.gn_partial != nullptr, rb = a.rowbias != nullptr;
+    FIE_REQUIRE(!gn || a.gn_cg == 4 || a.gn_cg == 8 || a.gn_cg == 16, "halo-resident conv: GroupNorm sums need 4, 8 or 16 channels per group");
+#define FIE_HALO2(RES, GN, RB, KH, ST) fie_launch(ctx, (conv_halo2_kernel<RES, GN, RB, KH, ST>), grid, dim3(512), kLdsHalo, a)
+#define FIE_HALO2_KH(KH)                                                                   \
+    do {                                                                                   \
+        if (rb && gn) FIE_HALO2(false, true, true, KH, false);                             \
+        else if (rb) FIE_HALO2(false, false, true, KH, false);                             \
+        else if (res && gn) FIE_HALO2(true, true, false, KH, false);                       \
+        else if (res) FIE_HALO2(true, false, false, KH, false);                            \
+        else if (gn) FIE_HALO2(false, true, false, KH, false);                             \
+        else FIE_HALO2(false, false, false, KH, false);                                    \
+    } while (0)
+    if (variant == 4) { if (res || gn) FIE_HALO2(true, true, false, false, true); else FIE_HALO2(false, false, false, false, true); }
+    else if (variant == 3) FIE_HALO2_KH(true);
+    else FIE_HALO2_KH(false);
+#undef FIE_HALO2_KH
+#undef FIE_HALO2
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

@@ -571,7 +571,7 @@ constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {42, 128
                               {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256},
                               {63, 256, 320}, {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
                               {52, 128, 128}, {47, 128, 96}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}, {48, 128, 80}, {64, 256, 320},
-                              {71, 256, 128}, {73, 256, 128}};
+                              {71, 256, 128}, {73, 256, 128}, {72, 256, 128}, {74, 256, 128}, {75, 256, 128}};
 
 // Heuristic tile code for a shape (the default; the autotuner below and the debug hooks can replace it).
 template <int MODE>
@@ -585,6 +585,12 @@ int heuristic_code(const fie_ctx* ctx, const GemmArgs& a, bool dma_ok) {
     int code;
     if (!dma_ok) {
         code = b42 >= cus ? 2 : 3;
+    } else if (MODE == 1 && fie_conv_halo_ok(a) && 4 * (int64_t)(a.M / 256) * ((a.N + 127) / 128) >= 3 * cus &&
+               std::find(std::begin(ctx->tune_exclude), std::end(ctx->tune_exclude), 72) == std::end(ctx->tune_exclude)) {      // fie_debug_tune_exclude("72"): the A/B switch
+        // stride-1 same-size convs on maps of whole 16x16 patches with enough (patch, 128-channel) tiles to fill the chip: the halo-resident kernel
+        // (conv_halo.hip; persistent, deferred stores).  Measured against every im2col code on the VAE's and the UNet's 64x64 / 128x128-latent
+        // shapes: -15 to -35 % (profiles/r04_halo_conv.md)
+        code = 72;
     } else if (MODE == 1) {
         if (!a.A2 && ((b256 >= cus && (a.N % 256 == 0 || (a.N % 128 != 0 && a.K >= 5760))) ||        // 256x256 phased: VAE 256/512-ch maps, 128x128-latent convs into 320 ch (not with 1x1 side inputs: ring kernels only)
             (a.N % 256 == 0 && a.K >= 8192 && 2 * b256 >= cus))) code = 81;                  // ... and the long-K upsampling convs of the 32x32 level
@@ -632,7 +638,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     FIE_REQUIRE(code < 40 || dma_ok, "tile code %d: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)", code);
     FIE_REQUIRE(!(a.taps2 && (code < 40 || a.w_scale)), "tile code %d: the 2x2 parity convs run on the f16 LDS-DMA kernels only", code);
     FIE_REQUIRE(!(MODE == 1 && a.A2 && (code < 40 || code == 81 || code == 82 || a.w_scale)), "tile code %d: conv + 1x1 side inputs run on the f16 ring kernels only", code);
-    FIE_REQUIRE(!((code == 71 || code == 73) && (MODE != 1 || !dma_ok || !fie_conv_halo_ok(a))), "tile code %d (halo-resident conv): stride-1 same-size 3x3 conv with H, W %% 16 == 0, Cin %% 64 == 0, f16 weights only", code);
+    FIE_REQUIRE(!((code >= 71 && code <= 75) && (MODE != 1 || !dma_ok || !fie_conv_halo_ok(a))), "tile code %d (halo-resident conv): stride-1 same-size 3x3 conv with H, W %% 16 == 0, Cin %% 64 == 0, f16 weights only", code);
     if (order < 0) {
         // Tile order = which operand an XCD re-streams past its 4 MiB L2.  Consecutive tile ids run on one XCD (xcd_remap), so an
         // XCD owns T/8 consecutive tiles: with n fastest that is `dm` row blocks x up to all column tiles, with m fastest the
@@ -672,8 +678,8 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     a.order = order;
     a.probe = ctx->gemm_probe;
     a.epi_prefetch = ctx->epi_prefetch;
-    a.stamps = (code == 97 || code == 98 || code == 94 || code == 73) ? ctx->gemm_stamps : nullptr;
-    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 90 ? "gemm3_kernel+prefetch" : code >= 80 ? "gemm8_kernel" : code == 71 || code == 73 ? "conv_halo_kernel" : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
+    a.stamps = (code == 97 || code == 98 || code == 94 || code == 73 || code == 74) ? ctx->gemm_stamps : nullptr;
+    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 90 ? "gemm3_kernel+prefetch" : code >= 80 ? "gemm8_kernel" : code >= 71 && code <= 75 ? (code == 71 || code == 73 ? "conv_halo_kernel" : "conv_halo2_kernel") : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
              t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
     if (split > 1) snprintf(ctx->last_kernel + strlen(ctx->last_kernel) - 1, 24, ", split-K %d)", split);
     if (MODE == 1)
@@ -722,6 +728,9 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
         case 94: launch_ring<128, 64, 3, M3, 4, false, true>(ctx, a, grid); break;
         case 71: return fie_launch_conv_halo(ctx, a, 0);
         case 73: return fie_launch_conv_halo(ctx, a, 1);
+        case 72: return fie_launch_conv_halo(ctx, a, 2);
+        case 75: return fie_launch_conv_halo(ctx, a, 3);
+        case 74: return fie_launch_conv_halo(ctx, a, 4);
         case 81: return fie_launch_gemm8(ctx, a, MODE == 1, 0);
         case 82: return fie_launch_gemm8(ctx, a, MODE == 1, 1);   // A/B: second DMA piece of a phase issued from inside the MFMA cluster (measured slower)
     }
@@ -731,8 +740,9 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
 
 // ---- per-shape autotune (fie_gemm_autotune): the first eager launch of a shape times every eligible tile on a scratch output
 // and remembers the fastest; later launches (and stream captures, which never tune) use the remembered code.  The candidates
-// differ in tile shape, ring depth and blocks per CU; every one accumulates K in the same order, so the choice does not change
-// the result.  Selection by measurement instead of by rule: which tile wins depends on how the grid quantises onto 256 CUs
+// differ in tile shape, ring depth and blocks per CU; every im2col tile accumulates K in the same order, so the choice among them does not change
+// the result (the halo-resident conv, code 72, sums chunk-major and a split-K code in slices: those two move the last f16 bit).  Selection by
+// measurement instead of by rule: which tile wins depends on how the grid quantises onto 256 CUs
 // and on whether two blocks share a CU (their epilogues and DMA issue overlap), see DESIGN.md.
 // Every timed launch sees what a launch inside the network sees: weights COLD (the 256 MB Infinity Cache is flushed by a
 // 384 MB memset; a UNet evaluation streams 2.6 GB of weights, so no layer finds its own in cache) and activations WARM (they
@@ -743,7 +753,7 @@ constexpr size_t kFlushBytes = 384u << 20;
 
 template <int MODE>
 int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
-    static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81, 63, 47, 48, 64};      // 47 (128x96): FIE_TUNE_47=0 leaves it out
+    static const int kRing[] = {43, 46, 42, 44, 51, 52, 54, 96, 81, 63, 47, 48, 64, 72};      // 47 (128x96): FIE_TUNE_47=0 leaves it out
     static const bool use47 = !(getenv("FIE_TUNE_47") && getenv("FIE_TUNE_47")[0] == '0');
     static const int kW8[] = {43, 42, 62, 52, 54};
     static const int kX8[] = {43, 42, 47, 51, 52, 54, 62, 63};
@@ -784,7 +794,7 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
     float t_best = t_guess * 0.97f;                          // a challenger has to win by 3 %
     const bool x8 = a.w_scale && a.a_scale != 0.f;
     const int* cand = x8 ? kX8 : a.w_scale ? kW8 : kRing;
-    const int ncand = x8 ? 8 : a.w_scale ? 5 : 13;
+    const int ncand = x8 ? 8 : a.w_scale ? 5 : 14;
     auto excluded = [&](int c) {
         for (int e : ctx->tune_exclude)
             if (e == c) return e != 0;
@@ -801,6 +811,7 @@ int autotune(fie_ctx* ctx, GemmArgs& a, int guess, bool dma_ok) {
         if (x8 && MODE == 1 && c == 63) continue;
         if (x8 && (c == 62 || c == 51) && 2 * blocks(c == 62 ? 256 : 128, 128) < ctx->num_cus) continue;
         if (c == 81 && MODE == 1 && a.A2) continue;            // side inputs: ring kernels only
+        if (c == 72 && (MODE != 1 || !fie_conv_halo_ok(a) || 2 * (int64_t)(a.M / 256) * ((a.N + 127) / 128) < ctx->num_cus)) continue;
         const float tc = time_of(c);
         if (verbose) fprintf(stderr, ", %d %.1f", c, tc * 1e3f);
         if (tc < t_best) { t_best = tc; best = c; }

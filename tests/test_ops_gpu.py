@@ -561,6 +561,57 @@ def test_gemm_autotune_picks_by_measurement_and_keeps_results(fie):
     assert hip.last_gemm_kernel(fie) == rule_kernel
 
 
+@pytest.mark.parametrize("code", [71, 72])
+def test_halo_resident_conv(fie, code):
+    """csrc/conv_halo.hip (SURVEY 2.2 K1 "LDS-staged halo tiles"): the stride-1 3x3 conv with a 16x16 output patch's 18x18 halo resident in LDS per
+    64-channel chunk.  Code 71 = one tile per block with the shared epilogue, 72 = persistent blocks with deferred stores (the rule for eligible
+    shapes).  Against torch's fp32 conv2d with every epilogue option the resnets use (bias, per-image row bias, residual, GroupNorm sums for the
+    consumer); shapes with one and with several tiles per block (400 and 1 200 tiles on 256 CUs), two column tiles, two images; a conv the
+    kernel does not take (SiLU epilogue, 24x24 map) falls back / is refused; repeats are bit-identical (the race screen: tools/halo_race.py)."""
+    from fie_amd import hip
+    g = torch.Generator().manual_seed(code)
+    try:
+        for b, h, w, cin, cout, opts in [(2, 32, 48, 128, 128, "bias,res"), (2, 64, 64, 256, 256, "bias,gn"), (1, 320, 320, 128, 128, "bias,res,gn"),
+                                         (2, 160, 240, 128, 256, "bias,rowbias,gn"), (1, 48, 32, 192, 320, "bias,rowbias"), (1, 16, 16, 64, 128, "")]:
+            x = torch.randn(b, h, w, cin, generator=g).half().to(DEV)
+            wt = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
+            bias = torch.randn(cout, generator=g).half().to(DEV) if "bias" in opts else None
+            res = torch.randn(b, h, w, cout, generator=g).half().to(DEV) if "res" in opts else None
+            rb = torch.randn(b, cout, generator=g).half().to(DEV) if "rowbias" in opts else None
+            wp = fie.pack_conv3x3(wt.to(DEV))
+            ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float().to(DEV), bias.float() if bias is not None else None, padding=1)
+            if rb is not None:
+                ref = ref + rb.float()[:, :, None, None]
+            if res is not None:
+                ref = ref + res.float().permute(0, 3, 1, 2)
+            fie.force_tile(code)
+            outs = [fie.conv3x3(x, wp, cout, bias=bias, residual=res, rowbias=rb, gn_groups=32 if "gn" in opts else None) for _ in range(6)]
+            assert "conv_halo" in hip.last_gemm_kernel(fie), hip.last_gemm_kernel(fie)
+            y = outs[0]
+            assert rel_err(y.permute(0, 3, 1, 2), ref) < 3e-3, (code, b, h, w, cin, cout, opts)
+            assert all(torch.equal(o, y) for o in outs[1:]), (code, b, h, w, cin, cout, opts)
+            if "gn" in opts:
+                assert getattr(outs[-1], "_gn_tag", None) is not None
+                gam, bet = (1 + 0.2 * torch.randn(cout, generator=g)).half().to(DEV), (0.1 * torch.randn(cout, generator=g)).half().to(DEV)
+                fie.force_tile(0)
+                gn = fie.groupnorm(outs[-1], gam, bet, 32, 1e-5, True)          # consumes the sums the conv's tile ends wrote
+                gref = F.silu(F.group_norm(y.float().permute(0, 3, 1, 2), 32, gam.float(), bet.float(), 1e-5))
+                assert rel_err(gn.permute(0, 3, 1, 2), gref) < 4e-3, (code, opts)
+        # not this kernel's: a 24x24 map is refused when forced; an activation epilogue is served by the one-tile-per-block form
+        fie.force_tile(code)
+        x = torch.randn(1, 24, 24, 128, generator=g).half().to(DEV)
+        wp = fie.pack_conv3x3((torch.randn(128, 128, 3, 3, generator=g) * 0.03).half().to(DEV))
+        with pytest.raises(hip.FieError, match="halo-resident conv"):
+            fie.conv3x3(x, wp, 128)
+        x = torch.randn(1, 32, 32, 128, generator=g).half().to(DEV)
+        y = fie.conv3x3(x, wp, 128, act=hip.ACT_SILU)
+        assert hip.last_gemm_kernel(fie).startswith("conv_halo")
+        fie.force_tile(0)
+        assert rel_err(y, fie.conv3x3(x, wp, 128, act=hip.ACT_SILU).float()) < 3e-3
+    finally:
+        fie.force_tile(0)
+
+
 def test_split_k_in_launch_reduction(fie):
     """Split-K for the M = 2048 class (include/fie.h: fie_splitk_workspace; gemm_common.h: splitk_reduce): the K-steps of a tile are
     dealt to s blocks, the block that arrives last sums the fp32 slabs in slice order and runs the epilogue.  Checked: the result

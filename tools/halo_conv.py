@@ -22,11 +22,12 @@ SHAPES = [(1, 1024, 128, 128), (1, 1024, 256, 128), (1, 512, 256, 256), (1, 512,
           (1, 128, 512, 512), (2, 128, 320, 320), (2, 128, 640, 320), (2, 64, 640, 640)]
 
 
-def check():
+def check(code=71):
     g = torch.Generator(device=DEV).manual_seed(0)
     worst = 0.0
     for b, h, w, cin, cout, opts in [(1, 16, 16, 64, 128, ""), (2, 32, 48, 128, 128, "bias,res"), (1, 48, 32, 192, 320, "bias,rowbias,silu"), (2, 64, 64, 256, 512, "bias,gn"),
-                                     (1, 1024, 1024, 128, 128, "bias")]:
+                                     (2, 128, 128, 320, 320, "bias,rowbias,gn"), (2, 64, 64, 640, 640, "bias,res,gn"), (1, 512, 512, 128, 256, "res"),
+                                     (1, 1024, 1024, 128, 128, "bias,res,gn"), (1, 1024, 1024, 128, 128, "bias")]:
         x = torch.randn(b, h, w, cin, generator=g, device=DEV, dtype=torch.float16)
         wt = torch.randn(cout, cin, 3, 3, generator=g, device=DEV, dtype=torch.float16) * (9 * cin) ** -0.5
         bias = torch.randn(cout, generator=g, device=DEV, dtype=torch.float16) if "bias" in opts else None
@@ -40,23 +41,23 @@ def check():
             ref = F.silu(ref)
         if res is not None:
             ref = ref + res.float().permute(0, 3, 1, 2)
-        ctx.force_tile(71)
+        ctx.force_tile(code)
         y = ctx.conv3x3(x, wp, cout, bias=bias, residual=res, rowbias=rb, act=hip.ACT_SILU if "silu" in opts else hip.ACT_NONE, gn_groups=32 if "gn" in opts else None)
         assert "conv_halo" in hip.last_gemm_kernel(ctx), hip.last_gemm_kernel(ctx)
+        torch.cuda.synchronize()
         err = ((y.float().permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max()).item()
         ctx.force_tile(0)
         y0 = ctx.conv3x3(x, wp, cout, bias=bias, residual=res, rowbias=rb, act=hip.ACT_SILU if "silu" in opts else hip.ACT_NONE)
         err0 = ((y0.float().permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max()).item()
         extra = ""
-        if "gn" in opts:
+        if "gn" in opts and getattr(y, "_gn_tag", None) is not None:
             gam, bet = torch.ones(cout, device=DEV, dtype=torch.float16), torch.zeros(cout, device=DEV, dtype=torch.float16)
-            assert getattr(y, "_gn_tag", None) is not None
             gn = ctx.groupnorm(y, gam, bet, 32, 1e-5, True)
             gref = F.silu(F.group_norm(y.float().permute(0, 3, 1, 2), 32, eps=1e-5))
             e2 = ((gn.float().permute(0, 3, 1, 2) - gref).abs().max() / gref.abs().max()).item()
             extra = f", GroupNorm from the epilogue's sums rel err {e2:.2e}"
             worst = max(worst, e2)
-        print(f"check B={b} {h}x{w} {cin}->{cout} [{opts}]: halo rel err {err:.2e} (rule kernel {err0:.2e}){extra}", flush=True)
+        print(f"check code {code} ({hip.last_gemm_kernel(ctx).split(' (')[0]}) B={b} {h}x{w} {cin}->{cout} [{opts}]: halo rel err {err:.2e} (rule kernel {err0:.2e}){extra}", flush=True)
         worst = max(worst, err)
     assert worst < 4e-3, worst
     print("correctness ok", flush=True)
@@ -137,7 +138,9 @@ if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     codes = [int(c) for c in args[0].split(",")] if args else [0, 71, 52, 96, 81]
     shapes = SHAPES[:3] if "--quick" in sys.argv else SHAPES
-    check()
+    for c in codes:
+        if 71 <= c <= 75:
+            check(c)
     if "--stamps" in sys.argv:
         stamps(shapes[:4])
     bench(codes, shapes)
