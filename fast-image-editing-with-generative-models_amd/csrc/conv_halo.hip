@@ -19,8 +19,8 @@
 // one pixel, the layout gemm_common.h's epilogue stores).  Fragment j of a wave = the 16 pixels of patch row wm * 4 + j, so its rows are OW apart
 // in the [B * OH * OW, N] output: GemmArgs::frag_ld.
 //
-// LDS (133,120 B): two halo buffers of 41 pieces x 1 KiB (324 pixels x 128 B, piece = 8 pixels), a 1 KiB dump for the seven piece slots that
-// have no piece (8 waves x 6 slots = 48 >= 41), three weight stages of 128 rows x 128 B.  Halo image: pixel p = hy * 18 + hx at byte p * 128, its
+// LDS (133,120 B): three weight stages of 128 rows x 128 B, two halo buffers of 41 pieces x 1 KiB (324 pixels x 128 B, piece = 8 pixels), a 1 KiB
+// dump for the seven piece slots that have no piece (8 waves x 6 slots = 48 >= 41).  Halo image: pixel p = hy * 18 + hx at byte p * 128, its
 // eight 16-byte channel chunks XOR-swizzled by (hx & 7) -- applied on the SOURCE chunk of the LDS-DMA (the destination of a wave's DMA is linear)
 // and on the fragment reads; the 16 lanes of a ds_read_b128 group then cover all 16 slots of a 256-byte bank row for every tap (checked by
 // enumeration: tools/halo_bank_check.py).  Weight stages: the ring kernels' image (row r at r * 128, chunks swizzled by r & 7).
@@ -50,9 +50,12 @@ constexpr int HSLOTS = 6;                       // halo piece slots per wave and
 constexpr int BNH = 128;                        // output channels per block
 constexpr int STH = 3;                          // weight stages
 constexpr int WSTAGE_B = BNH * 128;             // 16,384 bytes
-constexpr int DUMP_OFF = 2 * HALO_B;
-constexpr int WRING_OFF = DUMP_OFF + 1024;
-constexpr int kLdsHalo = WRING_OFF + STH * WSTAGE_B;      // 133,120 bytes
+// LDS: [three weight stages][halo 0][halo 1][dump].  The ring comes FIRST so that stage * 16 KiB + fragment * 2 KiB fits the 16-bit offset field of
+// ds_read_b128: two per-lane base registers serve every weight fragment read (behind the halos the six stage bases lived in six registers)
+constexpr int WRING_OFF = 0;
+constexpr int HALO_OFF = STH * WSTAGE_B;                  // 49,152
+constexpr int DUMP_OFF = HALO_OFF + 2 * HALO_B;
+constexpr int kLdsHalo = DUMP_OFF + 1024;                 // 133,120 bytes
 constexpr int RWH = BNH / 64;                   // weight pieces per wave and K-step (16 pieces of 8 rows over 8 waves)
 
 // DMA instructions a wave issues in the load segment of tap T: weights of K-step kt + 2 (none in the last chunk's taps 7, 8: past the end),
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
     }
     auto halo_dst = [&](int i, int buf) -> half_t* {          // slots past the last piece write zeros into the dump
         const int q = wave + 8 * i;
-        return reinterpret_cast<half_t*>(lds + (q < HPIECES ? buf * HALO_B + q * 1024 : DUMP_OFF));
+        return reinterpret_cast<half_t*>(lds + (q < HPIECES ? HALO_OFF + buf * HALO_B + q * 1024 : DUMP_OFF));
     };
     // ---- weight DMA: piece wave + 8 i = rows (wave + 8 i) * 8 .. + 7 of the block's 128 weight rows
     const int lr = lane >> 3;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
         }
         if constexpr (n_h(LAST, T) > 0) bload16(rs_a, halo_dst(T, (c + 1) & 1), h_off[T], (unsigned)(c + 1) * (BK * 2));
         stamp(0);
-        const char* const hal = lds + hb;
+        const char* const hal = lds + HALO_OFF + hb;
         const char* const wst = lds + WRING_OFF + STAGE * WSTAGE_B;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
@@ -238,8 +241,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
 //     (taps 0..7), where they ride on the counted waits like any DMA piece: no wave ever waits for a store, and the chip's write traffic is
 //     spread over the K loop instead of coming in bursts;
 //   * RES: the residual tile (the resnet's identity shortcut, upstream resnet.py: output = conv2(h) + input) is loaded sixteen 8-byte pieces per
-//     lane in taps 2..7 of the tile's LAST chunk, i.e. while the deferred outputs' registers are free again (they are stored during the first
-//     chunk; Cin >= 128: the first chunk is never the last).
+//     lane inside the MFMA segment of the tile's LAST K-step, into the registers the deferred outputs left in the first chunk (Cin >= 128: the
+//     first chunk is never the last).
 // Every vector-memory instruction between two counted waits is issued unconditionally (out-of-range lanes and absent operands go through the
 // descriptors' range check), so the vmcnt immediates stay compile-time constants per (chunk kind, tap); after the one irregular event (the row
 // bias of another image) the wave drains completely, which is always safe.
@@ -247,22 +250,27 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
 constexpr int K_FIRST = 0, K_MID = 1, K_LAST_F = 2, K_LAST_N = 3;      // chunk kinds: first (stores), middle, last with / without a next tile to prefetch
 constexpr int n2_w(int kind, int t) { return kind == K_LAST_N && t + 2 > 8 ? 0 : RWH; }
 constexpr int n2_h(int kind, int t) { return kind != K_LAST_N && t < HSLOTS ? 1 : 0; }
-constexpr int n2_st(int kind, int t) { return kind == K_FIRST && t < 8 ? 2 : 0; }
-constexpr int rl_cnt(int t) { return t >= 2 && t <= 5 ? 3 : (t == 6 || t == 7) ? 2 : 0; }
-constexpr int rl_first(int t) { int n = 0; for (int u = 0; u < t; ++u) n += rl_cnt(u); return n; }
-constexpr int n2_rl(bool res, int kind, int t) { return res && kind >= K_LAST_F ? rl_cnt(t) : 0; }
-// LOADS (LDS-DMA pieces, residual loads) issued BEHIND the weights in tap t's load segment.  STORES are deliberately not counted: measured in round 4
-// (tools/halo_race.py), a store does not reliably keep its place in the vmcnt order relative to LDS-DMA loads -- stores whose lanes are (mostly)
-// dropped by the range check retire early, and a wait that counted them let a weight piece through unretired about once in 500 launches.  Counting
-// loads only is safe either way: stores that retire early are not in the count, stores that are still pending only make the wait stricter.
-constexpr int n2_tail(bool res, int kind, int t) { return n2_h(kind, t) + n2_rl(res, kind, t); }
-// vmcnt that retires the weights of K-step kt + 1 (issued first in tap t - 1's load segment; tap 8 of every kind issues no load behind its weights)
-constexpr int n2_wait(bool res, int kind, int t) { return (t > 0 ? n2_tail(res, kind, t - 1) : 0) + n2_w(kind, t) + n2_tail(res, kind, t); }
-static_assert(rl_first(8) == 16 && n2_tail(true, K_LAST_F, 8) == 0 && n2_tail(true, K_FIRST, 8) == 0 && n2_st(K_FIRST, 8) == 0, "sixteen residual loads; tap 8 carries nothing behind its weights");
+// VAR (switches of v2): 2 = ST16: sixteen-byte stores (two fragments' halves exchanged by v_permlane16_swap: 8 stores per wave and tile, one per tap);
+// 4 = STM: the stores are issued from inside the MFMA segment; 8 = IM: EVERY vector-memory instruction of a K-step is issued from inside the MFMA segment
+constexpr int n2_st(int var, int kind, int t) { return kind == K_FIRST && t < 8 ? ((var & 2) ? 1 : 2) : 0; }
+// LOADS (LDS-DMA pieces) issued BEHIND the weights in tap t.  STORES are deliberately not counted: measured in round 4
+// (tools/halo_race.py; profiles/r04_halo_conv_stores_do_not_keep_vmcnt_order.md), a store does not reliably keep its place in the vmcnt order
+// relative to LDS-DMA loads -- with the deferred stores counted, a wait let a weight piece through unretired about once in 500 launches (8-byte
+// stores of whole lanes; range-dropped dummies and the mostly-dropped GroupNorm stores far more often).  Counting loads only is safe either way:
+// stores that retire early are not in the count, stores still pending only make the wait stricter.
+constexpr int n2_tail(bool res, int kind, int t) { return n2_h(kind, t); }
+// vmcnt that retires the weights of K-step kt + 1 (issued first among tap t - 1's instructions; tap 8 of every kind issues no load behind its
+// weights).  IM: tap t issues nothing before its wait (its instructions go out in the MFMA segment behind it)
+constexpr int n2_wait(int var, bool res, int kind, int t) {
+    return (t > 0 ? n2_tail(res, kind, t - 1) : 0) + ((var & 8) ? 0 : n2_w(kind, t) + n2_tail(res, kind, t));
+}
+static_assert(n2_tail(true, K_LAST_F, 8) == 0 && n2_tail(true, K_FIRST, 8) == 0 && n2_st(0, K_FIRST, 8) == 0, "tap 8 carries nothing behind its weights");
 
-template <bool RES, bool GN, bool RB, bool KH1L, bool STAMP>
+template <bool RES, bool GN, bool RB, int VAR, bool STAMP>
 __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
     constexpr int FM = 4, FN = 4, WN = 64;
+    constexpr bool ST16 = (VAR & 2) != 0, STM = (VAR & 4) != 0, IM = (VAR & 8) != 0;
+    static_assert(!RES || true, "");
     extern __shared__ __attribute__((aligned(16))) half_t smem[];
     char* const lds = reinterpret_cast<char*>(smem);
 
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
     };
     auto halo_dst = [&](int i, int buf) -> half_t* {
         const int q = wave + 8 * i;
-        return reinterpret_cast<half_t*>(lds + (q < HPIECES ? buf * HALO_B + q * 1024 : DUMP_OFF));
+        return reinterpret_cast<half_t*>(lds + (q < HPIECES ? HALO_OFF + buf * HALO_B + q * 1024 : DUMP_OFF));
     };
     const int lr = lane >> 3;
     const unsigned w_base = (unsigned)(n0 + wave * 8 + lr) * (unsigned)p.ldw * 2u + (unsigned)((lane & 7) ^ lr) * 16u;
@@ -349,6 +357,9 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
         }
     }
     // byte offset of (first fragment row, this lane's first channel) in a [M, ld] matrix; fragment row j is j * OW * ld * 2 further
+    auto row_off16 = [&](int m0, int64_t ld) -> unsigned {      // ST16: this lane stores pixel row (fq & 1) of a fragment pair, channels (fq >> 1) * 8 .. + 7 of the fragment
+        return ((unsigned)(m0 + (wm * FM + (fq & 1)) * p.OW + fr) * (unsigned)ld + (unsigned)(n0 + wn * WN + (fq >> 1) * 8)) * 2u;
+    };
     auto row_off = [&](int m0, int64_t ld) -> unsigned {
         return ((unsigned)(m0 + wm * FM * p.OW + fr) * (unsigned)ld + (unsigned)ncol) * 2u;        // N % 128 == 0 (launcher): every wave's channels are inside the matrix
     };
@@ -369,6 +380,7 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
         for (int j = 0; j < FM; ++j) outp[i][j] = (u32x2){0u, 0u};
 
     unsigned seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;     // STAMP: [0] DMA / store issue, [1] reads, [2] wait + barrier, [3] MFMA, [4] barrier, [5] prologue, [6] flush, [7] tile-end math
+    unsigned kseg[4] = {0, 0, 0, 0};                           // STAMP: whole K-steps by chunk kind (first = stores, middle, last with / without prefetch)
     auto stamp = [&](int i) {
         if constexpr (STAMP) {
             __builtin_amdgcn_sched_barrier(0);
@@ -383,9 +395,6 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
     const int nchunks = p.Cin / BK;                            // >= 2 (checked by the launcher)
     int tile = bid, m0 = 0, img = 0, y0 = 0, x0 = 0, img_rb = -1;
     geom(tile, m0, img, y0, x0);
-    unsigned h_off[HSLOTS];
-#pragma unroll
-    for (int i = 0; i < HSLOTS; ++i) h_off[i] = halo_off(i, img, y0, x0);
     // the bias has landed before anything else is in flight (its registers are read at every tile end)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
 
     // ---- prologue: the first tile's first halo, the weights of its K-steps 0 and 1
 #pragma unroll
-    for (int i = 0; i < HSLOTS; ++i) bload16(rs_a, halo_dst(i, 0), h_off[i], 0u);
+    for (int i = 0; i < HSLOTS; ++i) bload16(rs_a, halo_dst(i, 0), halo_off(i, img, y0, x0), 0u);
     issue_w(0, 0u);
     issue_w(1, cin2);
     wait_vm_barrier<RWH>();
@@ -411,33 +420,55 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
         constexpr int T = decltype(tapc)::value;
         constexpr int KY = T / 3, KX = T % 3;
         constexpr int STAGE = T % STH, FILL = (T + 2) % STH;
-        // ---- load segment: weights of K-step kt + 2, a halo piece, two deferred stores, residual loads (n2_wait counts the loads)
-        if constexpr (n2_w(KIND, T) > 0) {
+        const unsigned tk0 = tprev;
+        // ---- what this K-step issues besides its fragment reads: weights of K-step kt + 2 (two pieces), a halo piece, deferred stores, residual loads.
+        // In the load segment (default), or -- IM -- from inside the MFMA segment, one instruction behind every fourth MFMA: a vector-memory
+        // instruction costs ~60 cycles of issue among MFMAs against 100-200 in a load segment that also reads 16 fragments (MI355X_MICROARCH.md,
+        // cycle constants), and the load segment is what the MFMA segment of the other wave group waits for
+        auto issue_wp = [&](int i) {
             constexpr int T2 = (T + 2) % 9;
             const int c2 = T + 2 > 8 ? (KIND >= K_LAST_F ? 0 : c + 1) : c;
-            issue_w(FILL, (unsigned)T2 * cin2 + (unsigned)c2 * (BK * 2));
-        }
-        if constexpr (n2_h(KIND, T) > 0) {
-            if constexpr (KIND == K_LAST_F) bload16(rs_a, halo_dst(T, hpf_buf), halo_off(T, imgn, y0n, x0n), 0u);      // the next tile's first halo: offsets computed here (6 VGPRs saved)
-            else bload16(rs_a, halo_dst(T, hpf_buf), h_off[T], (unsigned)(c + 1) * (BK * 2));
-        }
-        if constexpr (n2_st(KIND, T) > 0) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                constexpr int K0 = 2 * T;
-                const int k = K0 + s, j = k / FN, i = k % FN;
+            bload16(rs_w, reinterpret_cast<half_t*>(lds + WRING_OFF + FILL * WSTAGE_B + (wave + 8 * i) * 1024), w_base + (unsigned)i * w_step,
+                    (unsigned)T2 * cin2 + (unsigned)c2 * (BK * 2));
+        };
+        auto issue_h = [&]() {
+            if constexpr (KIND == K_LAST_F) bload16(rs_a, halo_dst(T, hpf_buf), halo_off(T, imgn, y0n, x0n), 0u);      // the next tile's first halo: offsets computed at use from the packed slot register
+            else bload16(rs_a, halo_dst(T, hpf_buf), halo_off(T, img, y0, x0), (unsigned)(c + 1) * (BK * 2));        // this tile's next chunk
+        };
+        auto store1 = [&](int s) {
+            if constexpr (ST16) {                                // store T = (fragment pair T / 4, channel fragment T % 4): 16 B per lane
+                constexpr int JJ = T / FN, I = T % FN;
+                u32x4 v = {outp[I][2 * JJ][0], outp[I][2 * JJ][1], outp[I][2 * JJ + 1][0], outp[I][2 * JJ + 1][1]};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, ro_prev + (unsigned)(2 * JJ) * c_jstep + (unsigned)(I * 32), 0, 0);
+            } else {
+                const int k = 2 * T + s, j = k / FN, i = k % FN;
                 __builtin_amdgcn_raw_buffer_store_b64(outp[i][j], rs_c, ro_prev + (unsigned)j * c_jstep + (unsigned)(i * 32), 0, 0);
             }
-        }
-        if constexpr (n2_rl(RES, KIND, T) > 0) {
-#pragma unroll
-            for (int s = 0; s < rl_cnt(T); ++s) {
-                const int k = rl_first(T) + s, j = k / FN, i = k % FN;
-                outp[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, rr_cur + (unsigned)j * r_jstep + (unsigned)(i * 32), 0, 0);
-            }
-        }
+        };
+        // RES: the tile's residual values, all sixteen 8-byte loads per lane, go out in the MFMA segment of the tile's LAST K-step (two behind every
+        // MFMA group): the registers they land in are free by then (the deferred outputs left them in the first chunk), their latency runs under the
+        // MFMAs and the barrier, and no counted wait lies between their issue and their use at the tile end (where every older DMA has landed too)
+        auto resload1 = [&](int k) {
+            const int j = k / FN, i = k % FN;
+            outp[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, rr_cur + (unsigned)j * r_jstep + (unsigned)(i * 32), 0, 0);
+        };
+        constexpr int NW_ = n2_w(KIND, T), NH_ = n2_h(KIND, T), NS_ = n2_st(VAR, KIND, T);
+        constexpr bool RLT = RES && KIND >= K_LAST_F && T == 8;
+        // slot g (0..7) of the MFMA segment: the instruction issued behind MFMA group g (IM), or everything at once in the load segment
+        auto slot = [&](auto gc) {
+            constexpr int Gs = decltype(gc)::value;
+            if constexpr (Gs < 2) { if constexpr (NW_ > 0) issue_wp(Gs); }
+            else if constexpr (Gs == 2) { if constexpr (NH_ > 0) issue_h(); }
+            else if constexpr (Gs < 5) { if constexpr (Gs - 3 < NS_) store1(Gs - 3); }
+        };
+        auto all_slots = [&](bool loads, bool stores_too) {
+            if (loads) { slot(std::integral_constant<int, 0>{}); slot(std::integral_constant<int, 1>{}); slot(std::integral_constant<int, 2>{}); }
+            if (stores_too) { slot(std::integral_constant<int, 3>{}); slot(std::integral_constant<int, 4>{}); }
+        };
+        // ---- load segment
+        if constexpr (!IM) all_slots(true, !STM);
         stamp(0);
-        const char* const hal = lds + hb;
+        const char* const hal = lds + HALO_OFF + hb;
         const char* const wst = lds + WRING_OFF + STAGE * WSTAGE_B;
         auto reads = [&](int kh) {
 #pragma unroll
@@ -446,28 +477,30 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
             for (int j = 0; j < FM; ++j) fa[kh][j] = *reinterpret_cast<const f16x8*>(hal + a_rd[KX][kh] + (j + KY) * HP * 128);
         };
         reads(0);
-        if constexpr (!KH1L) reads(1);
+        reads(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(1);
-        wait_vm_barrier<n2_wait(RES, KIND, T)>();
+        wait_vm_barrier<n2_wait(VAR, RES, KIND, T)>();
         stamp(2);
-        // ---- MFMA segment (KH1L: the second k half's fragments are read here, under the first half's MFMAs)
+        // ---- MFMA segment
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (KH1L) { reads(1); __builtin_amdgcn_sched_barrier(0); }
         __builtin_amdgcn_s_setprio(1);
+        auto group = [&](auto gc) {                              // MFMA group g = (k half g / 4, channel fragment g % 4): four row fragments
+            constexpr int Gs = decltype(gc)::value, kh = Gs / FN, i = Gs % FN;
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kh][i], fa[kh][j], acc[i][j], 0, 0, 0);
-            if constexpr (KH1L) { if (kh == 0) __builtin_amdgcn_sched_barrier(0); }
-        }
+            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kh][i], fa[kh][j], acc[i][j], 0, 0, 0);
+            if constexpr (RLT) { __builtin_amdgcn_sched_barrier(0); resload1(2 * Gs); resload1(2 * Gs + 1); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (IM) { __builtin_amdgcn_sched_barrier(0); slot(gc); __builtin_amdgcn_sched_barrier(0); }
+            else if constexpr (STM && (Gs == 3 || Gs == 4)) { __builtin_amdgcn_sched_barrier(0); slot(gc); __builtin_amdgcn_sched_barrier(0); }
+        };
+        group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{}); group(std::integral_constant<int, 2>{}); group(std::integral_constant<int, 3>{});
+        group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{}); group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{});
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         stamp(3);
         __builtin_amdgcn_s_barrier();
         stamp(4);
+        if constexpr (STAMP) kseg[KIND] += tprev - tk0;
     };
     auto chunk = [&](auto kindc, int c, unsigned hb, int hpf_buf) {
         kstep(kindc, std::integral_constant<int, 0>{}, c, hb, hpf_buf);
@@ -487,13 +520,17 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
         auto as_h4 = [](u32x2 v) { f16x4 h; __builtin_memcpy(&h, &v, 8); return h; };
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
-            const f16x4 b = as_h4(bv[i]);
+            u32x2 bo = bv[i];
+            asm volatile("" : "+v"(bo));                     // opaque: keeps the f16 -> f32 conversions of the bias from being hoisted into 16 loop-invariant registers
+            const f16x4 b = as_h4(bo);
 #pragma unroll
             for (int j = 0; j < FM; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)b[r];
             if constexpr (RB) {
-                const f16x4 rb = as_h4(rbv[i]);
+                u32x2 ro_ = rbv[i];
+                asm volatile("" : "+v"(ro_));
+                const f16x4 rb = as_h4(ro_);
 #pragma unroll
                 for (int j = 0; j < FM; ++j)
 #pragma unroll
@@ -544,10 +581,10 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
                     const float vs = lane == 0 ? ts[0] : lane == 1 ? ts[1] : lane == 2 ? ts[2] : ts[3];
                     const float vq = lane == 0 ? tq[0] : lane == 1 ? tq[1] : lane == 2 ? tq[2] : tq[3];
                     const bool ok = lane < ngrp && nfrag + lane * p.gn_cg < p.N;
-                    const unsigned off = ok ? (unsigned)(((imgc * gn_nch + chunk) * p.gn_G + nfrag / p.gn_cg + lane) * 8) : kOob;
                     u32x2 bits;
                     const float2 v2 = make_float2(vs, vq);
                     __builtin_memcpy(&bits, &v2, 8);
+                    const unsigned off = ok ? (unsigned)(((imgc * gn_nch + chunk) * p.gn_G + nfrag / p.gn_cg + lane) * 8) : kOob;
                     __builtin_amdgcn_raw_buffer_store_b64(bits, rs_g, off, 0, 0);
                 }
             }
@@ -562,6 +599,22 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
                 __builtin_memcpy(&outp[i][j], &o, 8);
                 acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+        if constexpr (ST16) {
+            // fragments (i, 2 jj) and (i, 2 jj + 1): v_permlane16_swap exchanges the odd 16-lane rows of the first with the even rows of the second, dword by
+            // dword.  Afterwards a lane of an even row (fq 0 / 2) holds 8 consecutive channels (fq / 2) * 8 .. + 7 of pixel row 2 jj, a lane of an odd row
+            // the same of pixel row 2 jj + 1: one 16-byte store instead of two 8-byte ones
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int jj = 0; jj < FM / 2; ++jj)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        unsigned a = outp[i][2 * jj][d], b = outp[i][2 * jj + 1][d];
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+                        outp[i][2 * jj][d] = a;
+                        outp[i][2 * jj + 1][d] = b;
+                    }
+        }
     };
 
     int g = 0;                                                  // chunks run so far: halo buffer g & 1 is being read, (g + 1) & 1 being filled
@@ -596,32 +649,42 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
         else chunk(std::integral_constant<int, K_LAST_N>{}, nchunks - 1, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
         ++g;
         tile_end(m0, img);
-        ro_prev = row_off(m0, p.ldc);
+        ro_prev = ST16 ? row_off16(m0, p.ldc) : row_off(m0, p.ldc);
         stamp(7);
         if (!have_next) break;
         tile = next; m0 = m0n; img = imgn; y0 = y0n; x0 = x0n;
-#pragma unroll
-        for (int i = 0; i < HSLOTS; ++i) h_off[i] = halo_off(i, img, y0, x0);
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();                // pairs with group 1's last barrier
     // ---- flush: the last tile's sixteen stores
+    if constexpr (ST16) {
 #pragma unroll
-    for (int j = 0; j < FM; ++j)
+        for (int jj = 0; jj < FM / 2; ++jj)
 #pragma unroll
-        for (int i = 0; i < FN; ++i) __builtin_amdgcn_raw_buffer_store_b64(outp[i][j], rs_c, ro_prev + (unsigned)j * c_jstep + (unsigned)(i * 32), 0, 0);
+            for (int i = 0; i < FN; ++i) {
+                u32x4 v = {outp[i][2 * jj][0], outp[i][2 * jj][1], outp[i][2 * jj + 1][0], outp[i][2 * jj + 1][1]};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, ro_prev + (unsigned)(2 * jj) * c_jstep + (unsigned)(i * 32), 0, 0);
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int i = 0; i < FN; ++i) __builtin_amdgcn_raw_buffer_store_b64(outp[i][j], rs_c, ro_prev + (unsigned)j * c_jstep + (unsigned)(i * 32), 0, 0);
+    }
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(6);
         if (p.stamps && lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) p.stamps[((size_t)bid * 8 + wave) * 8 + i] = seg[i];
+            for (int i = 0; i < 8; ++i) p.stamps[((size_t)bid * 8 + wave) * 12 + i] = seg[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p.stamps[((size_t)bid * 8 + wave) * 12 + 8 + i] = kseg[i];
         }
     }
 }
 
-template <bool RES, bool GN, bool RB, bool KH1L, bool STAMP>
+template <bool RES, bool GN, bool RB, int VAR, bool STAMP>
 hipError_t halo2_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo2_kernel<RES, GN, RB, KH1L, STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo2_kernel<RES, GN, RB, VAR, STAMP>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo);
 }
 
 }  // namespace
@@ -629,20 +692,20 @@ hipError_t halo2_attr() {
 int fie_conv_halo_init(void) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo);
-    if (e == hipSuccess) e = halo2_attr<false, false, false, false, false>();
-    if (e == hipSuccess) e = halo2_attr<false, true, false, false, false>();
-    if (e == hipSuccess) e = halo2_attr<true, false, false, false, false>();
-    if (e == hipSuccess) e = halo2_attr<true, true, false, false, false>();
-    if (e == hipSuccess) e = halo2_attr<false, false, true, false, false>();
-    if (e == hipSuccess) e = halo2_attr<false, true, true, false, false>();
-    if (e == hipSuccess) e = halo2_attr<false, false, false, true, false>();
-    if (e == hipSuccess) e = halo2_attr<false, true, false, true, false>();
-    if (e == hipSuccess) e = halo2_attr<true, false, false, true, false>();
-    if (e == hipSuccess) e = halo2_attr<true, true, false, true, false>();
-    if (e == hipSuccess) e = halo2_attr<false, false, true, true, false>();
-    if (e == hipSuccess) e = halo2_attr<false, true, true, true, false>();
-    if (e == hipSuccess) e = halo2_attr<false, false, false, false, true>();
-    if (e == hipSuccess) e = halo2_attr<true, true, false, false, true>();
+    if (e == hipSuccess) e = halo2_attr<false, false, false, 6, false>();
+    if (e == hipSuccess) e = halo2_attr<false, true, false, 6, false>();
+    if (e == hipSuccess) e = halo2_attr<true, false, false, 6, false>();
+    if (e == hipSuccess) e = halo2_attr<true, true, false, 6, false>();
+    if (e == hipSuccess) e = halo2_attr<false, false, true, 6, false>();
+    if (e == hipSuccess) e = halo2_attr<false, true, true, 6, false>();
+    if (e == hipSuccess) e = halo2_attr<false, false, false, 0, false>();
+    if (e == hipSuccess) e = halo2_attr<false, true, false, 0, false>();
+    if (e == hipSuccess) e = halo2_attr<true, false, false, 0, false>();
+    if (e == hipSuccess) e = halo2_attr<true, true, false, 0, false>();
+    if (e == hipSuccess) e = halo2_attr<false, false, true, 0, false>();
+    if (e == hipSuccess) e = halo2_attr<false, true, true, 0, false>();
+    if (e == hipSuccess) e = halo2_attr<false, false, false, 6, true>();
+    if (e == hipSuccess) e = halo2_attr<true, true, false, 6, true>();
     if (e != hipSuccess) {
         fie_set_error("conv_halo: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return FIE_EHIP;
@@ -657,14 +720,18 @@ bool fie_conv_halo_ok(const GemmArgs& a) {
            a.OW % 16 == 0 && a.Cin % BK == 0 && a.Cin >= BK && !a.w_scale && a.K == 9 * a.Cin && !a.out_f8 && a.splitk <= 1;
 }
 
-// variant: 0 = v1 (one tile per block, code 71), 1 = v1 with stamps (73), 2 = v2 persistent + deferred stores (72), 3 = v2 with the second k half's
-// fragments read under the MFMAs (75), 4 = v2 with stamps (74)
+// variant: 0 = v1 (one tile per block, code 71), 1 = v1 with stamps (73), 2 = v2: persistent blocks, deferred 16-byte stores issued inside the MFMA
+// segments (72; with at most one tile per block it runs as v1: nothing to defer into), 4 = v2 with stamps (74), 5 = v2 with 8-byte stores issued in
+// the load segments (76: the first form, kept for A/B).  Measured and not kept (profiles/r04_halo_conv.md): the stores counted in the waits
+// (a race), every vector-memory instruction issued from inside the MFMA segment (no faster), the second k half's fragments read under the MFMAs
+// (slower)
 int fie_launch_conv_halo(fie_ctx* ctx, GemmArgs& a, int variant) {
     FIE_REQUIRE(fie_conv_halo_ok(a), "halo-resident conv: stride-1 same-size 3x3 conv with H, W %% 16 == 0 and Cin %% 64 == 0 only");
     a.frag_ld = a.OW;
     a.nbn = (a.N + BNH - 1) / BNH;
     a.nbm = (a.M / (a.OH * a.OW)) * (a.OH >> 4) * (a.OW >> 4);
     const int tiles = a.nbm * a.nbn;
+    if (variant >= 2 && tiles <= ctx->num_cus) variant = variant == 4 ? 1 : 0;      // one tile per block: the one-tile form (its epilogue is shorter than a tile end + a flush)
     // v2 stores during the first chunk and loads residuals in the last: two chunks at least; whole 128-channel column tiles (a wave whose channels lie
     // past N would issue stores / loads that the range check drops whole, and those do not keep the vmcnt order the counted waits rely on); row bias and
     // residual never come together (resnet conv1 / conv2); no activation / scale
@@ -683,20 +750,20 @@ int fie_launch_conv_halo(fie_ctx* ctx, GemmArgs& a, int variant) {
     const dim3 grid((unsigned)g);
     const bool res = a.res != nullptr, gn = a.gn_partial != nullptr, rb = a.rowbias != nullptr;
     FIE_REQUIRE(!gn || a.gn_cg == 4 || a.gn_cg == 8 || a.gn_cg == 16, "halo-resident conv: GroupNorm sums need 4, 8 or 16 channels per group");
-#define FIE_HALO2(RES, GN, RB, KH, ST) fie_launch(ctx, (conv_halo2_kernel<RES, GN, RB, KH, ST>), grid, dim3(512), kLdsHalo, a)
-#define FIE_HALO2_KH(KH)                                                                   \
+#define FIE_HALO2(RES, GN, RB, VAR, ST) fie_launch(ctx, (conv_halo2_kernel<RES, GN, RB, VAR, ST>), grid, dim3(512), kLdsHalo, a)
+#define FIE_HALO2_V(VAR)                                                                   \
     do {                                                                                   \
-        if (rb && gn) FIE_HALO2(false, true, true, KH, false);                             \
-        else if (rb) FIE_HALO2(false, false, true, KH, false);                             \
-        else if (res && gn) FIE_HALO2(true, true, false, KH, false);                       \
-        else if (res) FIE_HALO2(true, false, false, KH, false);                            \
-        else if (gn) FIE_HALO2(false, true, false, KH, false);                             \
-        else FIE_HALO2(false, false, false, KH, false);                                    \
+        if (rb && gn) FIE_HALO2(false, true, true, VAR, false);                            \
+        else if (rb) FIE_HALO2(false, false, true, VAR, false);                            \
+        else if (res && gn) FIE_HALO2(true, true, false, VAR, false);                      \
+        else if (res) FIE_HALO2(true, false, false, VAR, false);                           \
+        else if (gn) FIE_HALO2(false, true, false, VAR, false);                            \
+        else FIE_HALO2(false, false, false, VAR, false);                                   \
     } while (0)
-    if (variant == 4) { if (res || gn) FIE_HALO2(true, true, false, false, true); else FIE_HALO2(false, false, false, false, true); }
-    else if (variant == 3) FIE_HALO2_KH(true);
-    else FIE_HALO2_KH(false);
-#undef FIE_HALO2_KH
+    if (variant == 4) { if (res || gn) FIE_HALO2(true, true, false, 6, true); else FIE_HALO2(false, false, false, 6, true); }
+    else if (variant == 5) FIE_HALO2_V(0);
+    else FIE_HALO2_V(6);
+#undef FIE_HALO2_V
 #undef FIE_HALO2
     FIE_LAUNCH_CHECK();
     return FIE_OK;

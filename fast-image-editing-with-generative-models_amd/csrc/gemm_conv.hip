@@ -566,12 +566,14 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
 //   71 / 73        conv_halo_kernel (conv_halo.hip): a 16x16 output patch x 128 channels per block, the patch's 18x18 halo resident in LDS per
 //                  64-channel chunk, weights through a ring; stride-1 same-size convs with H, W % 16 == 0 only (73: with cycle stamps).
 //                  K is summed chunk-major (the im2col kernels: tap-major): equal to the other codes to rounding, not bit for bit
+//   72 / 74 / 76   conv_halo2_kernel: the same K loop in persistent blocks that prefetch their next tile and defer a tile's stores into the next
+//                  tile's first chunk (74: with cycle stamps, 76: the 8-byte-store form, A/B); THE RULE for eligible convs (heuristic_code)
 struct TileDim { int code, bm, bn; };
 constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {42, 128, 64}, {43, 64, 64},
                               {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256},
                               {63, 256, 320}, {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
                               {52, 128, 128}, {47, 128, 96}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}, {48, 128, 80}, {64, 256, 320},
-                              {71, 256, 128}, {73, 256, 128}, {72, 256, 128}, {74, 256, 128}, {75, 256, 128}};
+                              {71, 256, 128}, {73, 256, 128}, {72, 256, 128}, {74, 256, 128}, {76, 256, 128}};
 
 // Heuristic tile code for a shape (the default; the autotuner below and the debug hooks can replace it).
 template <int MODE>
@@ -598,6 +600,11 @@ int heuristic_code(const fie_ctx* ctx, const GemmArgs& a, bool dma_ok) {
         else if (a.N % 128 == 0 && a.K >= 5760 && b51 >= 100) code = 51;                     // 32x32-latent convs: 160 x (128x128), 8 waves
         else if (2 * b42 < 3 * cus) code = 43;                                               // stride-2 convs and other small grids
         else code = 42;
+    } else if (MODE == 0 && a.N % 320 == 0 && a.N >= 5120 && 4 * blocks(256, 320) >= 3 * cus) {
+        // the FF1 projections (M 2048 x N 10240: 256 tiles of 256x320 = one per CU; M 8192 x N 5120: two exact rounds): tile 64 measured 52-58 us
+        // on every box of round 3 against 65-80 us for 96 -- but the cold-timed tuner, starting from 96 as the rule, kept 96 on some boxes (one
+        // profile run of round 4: 79.7 us x 112 launches = +2.4 ms per edit).  As the RULE it needs a 3 % better challenger to be displaced.
+        code = 64;
     } else if (a.N % 256 == 0 && a.K >= 4096 && b256 >= cus) {
         code = 81;
     } else if (a.N % 128 == 0 && b62 >= 150 && (a.N >= 1536 || a.K >= 2048 || a.M >= 16384)) {
@@ -638,7 +645,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     FIE_REQUIRE(code < 40 || dma_ok, "tile code %d: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)", code);
     FIE_REQUIRE(!(a.taps2 && (code < 40 || a.w_scale)), "tile code %d: the 2x2 parity convs run on the f16 LDS-DMA kernels only", code);
     FIE_REQUIRE(!(MODE == 1 && a.A2 && (code < 40 || code == 81 || code == 82 || a.w_scale)), "tile code %d: conv + 1x1 side inputs run on the f16 ring kernels only", code);
-    FIE_REQUIRE(!((code >= 71 && code <= 75) && (MODE != 1 || !dma_ok || !fie_conv_halo_ok(a))), "tile code %d (halo-resident conv): stride-1 same-size 3x3 conv with H, W %% 16 == 0, Cin %% 64 == 0, f16 weights only", code);
+    FIE_REQUIRE(!((code >= 71 && code <= 76) && (MODE != 1 || !dma_ok || !fie_conv_halo_ok(a))), "tile code %d (halo-resident conv): stride-1 same-size 3x3 conv with H, W %% 16 == 0, Cin %% 64 == 0, f16 weights only", code);
     if (order < 0) {
         // Tile order = which operand an XCD re-streams past its 4 MiB L2.  Consecutive tile ids run on one XCD (xcd_remap), so an
         // XCD owns T/8 consecutive tiles: with n fastest that is `dm` row blocks x up to all column tiles, with m fastest the
@@ -679,7 +686,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     a.probe = ctx->gemm_probe;
     a.epi_prefetch = ctx->epi_prefetch;
     a.stamps = (code == 97 || code == 98 || code == 94 || code == 73 || code == 74) ? ctx->gemm_stamps : nullptr;
-    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 90 ? "gemm3_kernel+prefetch" : code >= 80 ? "gemm8_kernel" : code >= 71 && code <= 75 ? (code == 71 || code == 73 ? "conv_halo_kernel" : "conv_halo2_kernel") : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
+    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 90 ? "gemm3_kernel+prefetch" : code >= 80 ? "gemm8_kernel" : code >= 71 && code <= 76 ? (code == 71 || code == 73 ? "conv_halo_kernel" : "conv_halo2_kernel") : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
              t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
     if (split > 1) snprintf(ctx->last_kernel + strlen(ctx->last_kernel) - 1, 24, ", split-K %d)", split);
     if (MODE == 1)
@@ -729,7 +736,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
         case 71: return fie_launch_conv_halo(ctx, a, 0);
         case 73: return fie_launch_conv_halo(ctx, a, 1);
         case 72: return fie_launch_conv_halo(ctx, a, 2);
-        case 75: return fie_launch_conv_halo(ctx, a, 3);
+        case 76: return fie_launch_conv_halo(ctx, a, 5);
         case 74: return fie_launch_conv_halo(ctx, a, 4);
         case 81: return fie_launch_gemm8(ctx, a, MODE == 1, 0);
         case 82: return fie_launch_gemm8(ctx, a, MODE == 1, 1);   // A/B: second DMA piece of a phase issued from inside the MFMA cluster (measured slower)

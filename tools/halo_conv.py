@@ -80,7 +80,13 @@ def bench(codes, shapes):
         wp = ctx.pack_conv3x3(torch.randn(cout, cin, 3, 3, device=DEV, dtype=torch.float16) * (9 * cin) ** -0.5)
         bias = torch.randn(cout, device=DEV, dtype=torch.float16)
         out = torch.empty(b, h, h, cout, device=DEV, dtype=torch.float16)
-        fns = [lambda x=x: ctx.conv3x3(x, wp, cout, out=out, bias=bias) for x in xs]
+        if "--resgn" in sys.argv and cin == cout:           # the resnet's conv2: + identity shortcut, GroupNorm sums for the next block's norm1
+            res = torch.randn(b, h, h, cout, device=DEV, dtype=torch.float16)
+            fns = [lambda x=x: ctx.conv3x3(x, wp, cout, out=out, bias=bias, residual=res, gn_groups=32) for x in xs]
+        elif "--resgn" in sys.argv:                         # conv1: GroupNorm sums for norm2
+            fns = [lambda x=x: ctx.conv3x3(x, wp, cout, out=out, bias=bias, gn_groups=32) for x in xs]
+        else:
+            fns = [lambda x=x: ctx.conv3x3(x, wp, cout, out=out, bias=bias) for x in xs]
         flops = 2.0 * b * h * h * cout * cin * 9
         times = {c: [] for c in codes}
         names = {}
@@ -110,28 +116,34 @@ def bench(codes, shapes):
         print(f"conv B={b} {h}x{h} {cin}->{cout:4d}  " + "  ".join(cells), flush=True)
 
 
-def stamps(shapes):
-    """Where a K-step of the halo kernel spends its cycles (code 73): per-wave s_memtime sums, median over blocks, per K-step."""
+def stamps(shapes, code=73):
+    """Where a K-step of the halo kernel spends its cycles (code 73: v1, 74: v2): per-wave s_memtime sums, median over blocks, per K-step."""
     for b, h, cin, cout in shapes:
         x = torch.randn(b, h, h, cin, device=DEV, dtype=torch.float16)
         wp = ctx.pack_conv3x3(torch.randn(cout, cin, 3, 3, device=DEV, dtype=torch.float16) * (9 * cin) ** -0.5)
-        nblk = b * (h // 16) ** 2 * ((cout + 127) // 128)
-        buf = torch.zeros(nblk * 8 * 8, device=DEV, dtype=torch.int32)
+        ntile = b * (h // 16) ** 2 * ((cout + 127) // 128)
+        nblk = ntile if code == 73 else min(ntile, 256) // ((cout + 127) // 128) * ((cout + 127) // 128)
+        nslot = 8 if code == 73 else 12
+        buf = torch.zeros(nblk * 8 * nslot, device=DEV, dtype=torch.int32)
         ctx.gemm_stamps(buf)
-        ctx.force_tile(73)
+        ctx.force_tile(code)
         ctx.conv3x3(x, wp, cout)
         ctx.conv3x3(x, wp, cout)
         torch.cuda.synchronize()
         ctx.force_tile(0)
         ctx.gemm_stamps(None)
-        s = buf.view(nblk, 8, 8).float()
-        nk = 9 * cin // 64
+        s = buf.view(nblk, 8, nslot).float()
+        nk = 9 * cin // 64 * (ntile // nblk)
         med = s.median(dim=0).values            # [wave][segment]
-        names = ["DMA issue", "reads", "wait+barrier", "MFMA issue", "barrier", "prologue", "epilogue"]
+        names = ["DMA issue", "reads", "wait+barrier", "MFMA issue", "barrier", "prologue", "epilogue / flush", "tile-end math"]
         for grp, ws in (("group 0 (waves 0-3)", slice(0, 4)), ("group 1 (waves 4-7)", slice(4, 8))):
             m = med[ws].mean(dim=0)
             per = ", ".join(f"{names[i]} {m[i].item() / nk:6.0f}" for i in range(5))
-            print(f"stamps B={b} {h}x{h} {cin}->{cout} {grp}: per K-step: {per} | prologue {m[5].item():.0f} epilogue {m[6].item():.0f} cycles; K loop {sum(m[i].item() for i in range(5)):.0f}", flush=True)
+            print(f"stamps code {code} B={b} {h}x{h} {cin}->{cout} {grp}: per K-step: {per} | prologue {m[5].item():.0f} epilogue / flush {m[6].item():.0f} tile-end math {m[7].item() / (ntile // nblk):.0f} per tile; K loop {sum(m[i].item() for i in range(5)):.0f} cycles over {ntile // nblk} tiles", flush=True)
+            if nslot == 12:
+                tiles, nch = ntile // nblk, cin // 64
+                cnt = [9 * (tiles - 1), 9 * ((nch - 2) * tiles + 1), 9 * (tiles - 1), 9]       # K-steps per kind: first (tiles 2..), middle (+ the first tile's first chunk), last with prefetch, last without
+                print("      whole K-steps by chunk kind: " + ", ".join(f"{nm} {m[8 + k].item() / max(cnt[k], 1):.0f}" for k, nm in enumerate(["first (stores)", "middle", "last + next tile's prefetch", "last"])), flush=True)
 
 
 if __name__ == "__main__":
@@ -139,8 +151,9 @@ if __name__ == "__main__":
     codes = [int(c) for c in args[0].split(",")] if args else [0, 71, 52, 96, 81]
     shapes = SHAPES[:3] if "--quick" in sys.argv else SHAPES
     for c in codes:
-        if 71 <= c <= 75:
+        if 71 <= c <= 76:
             check(c)
     if "--stamps" in sys.argv:
-        stamps(shapes[:4])
+        stamps(shapes[:3], 73)
+        stamps(shapes[:3], 74)
     bench(codes, shapes)

@@ -36,6 +36,8 @@ def staged_bytes(desc):
     if not m:
         return None
     M, N, K, code = (int(v) for v in m.groups())
+    if code in (71, 72):          # halo-resident conv (csrc/conv_halo.hip): per K-step 128 weight rows x 128 B + a ninth of a 41 KB halo, per (16x16 patch, 128 channels) tile
+        return (M // 256) * -(-N // 128) * -(-K // 64) * (128 * 128.0 + 41984.0 / 9)
     t = TILE.get(code % 1000)
     if t is None:
         return None
