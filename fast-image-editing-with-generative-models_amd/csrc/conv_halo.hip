@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
     chunk(std::true_type{}, nchunks - 1);
     if (grp == 0) __builtin_amdgcn_s_barrier();                // pairs with group 1's last barrier
 
-    epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane);
+    epilogue<FM, FN, WM, WN, true, true>(p, acc, m0, n0, wm, wn, lane);
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(6);

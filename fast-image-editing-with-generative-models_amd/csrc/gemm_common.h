@@ -56,7 +56,6 @@ struct GemmArgs {
     // is m0 + (wm * FM + j) * frag_ld + fr with m0 = the patch's first pixel.  0 = the ordinary consecutive-row tile (16).
     int frag_ld;
 };
-__device__ __forceinline__ int frag_ld_of(const GemmArgs& p) { return p.frag_ld ? p.frag_ld : 16; }
 
 // oscat == 2: the block's parity comes from its (remapped) tile id; the four parity tiles of one output tile are neighbours in time and
 // share the input rows in L2.  Rewrites the by-value kernel argument and returns the tile id within the parity.
@@ -68,6 +67,10 @@ __device__ __forceinline__ int take_parity(GemmArgs& p, int bid) {
     p.gn_chunk0 = par * ((p.OH * p.OW) >> 5);
     return bid >> 2;
 }
+
+// f(integral_constant<int, 0>), f(integral_constant<int, 1>), ...: a loop whose index is a compile-time constant in every iteration
+template <class F, int... I>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * BK + ((chunk ^ (row & 7)) << 3); }
 
@@ -104,8 +107,7 @@ struct EpiPre {
 template <int FM, int FN, int WM, int WN>
 __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& p, EpiPre<FM, FN>& pre, int m0, int n0, int wm, int wn, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
-    const int fld = frag_ld_of(p);
-    const int mrow = m0 + wm * FM * fld + fr, ncol = n0 + wn * WN + fq * 4;
+    const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
     pre.on = true;
 #pragma unroll
     for (int i = 0; i < FN; ++i) pre.bias[i] = (u32x2){0u, 0u};                      // absent operands read as zero: the lean epilogue adds them unconditionally
@@ -122,7 +124,7 @@ __device__ __forceinline__ void epilogue_prefetch(const GemmArgs& p, EpiPre<FM, 
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.res), 0, (int)(((int64_t)(p.M - 1) * p.ldr + p.N) * 2), 0x00020000);
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
-            const int m = mrow + j * fld;
+            const int m = mrow + j * 16;
             const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldr * 2u : 0x80000000u;
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
@@ -217,13 +219,15 @@ __device__ __forceinline__ void epilogue_geglu_lean(const GemmArgs& p, f32x4 (&a
     }
 }
 
-template <int FM, int FN, int WM, int WN, bool BUF = false>
+// PATCH (conv_halo.hip only): the tile is a 16x16 output patch, fragment rows p.frag_ld = OW apart (GemmArgs::frag_ld); every other kernel compiles
+// the constant 16 (a runtime stride in here costs the big tiles their register allocation: measured, round 4)
+template <int FM, int FN, int WM, int WN, bool BUF = false, bool PATCH = false>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane, const EpiPre<FM, FN>* pre = nullptr) {
     const int fr = lane & 15, fq = lane >> 4;
     const bool have_pre = pre != nullptr && pre->on;
     if (p.probe == 4 && p.M > 0) return;                    // timing probe: no epilogue at all (p.M > 0 keeps the accumulators live)
     const bool geglu = p.act == FIE_ACT_GEGLU;
-    const int fld = frag_ld_of(p);                          // rows between consecutive fragments: 16, or OW for a 16x16 output patch (GemmArgs::frag_ld)
+    const int fld = PATCH ? p.frag_ld : 16;                 // rows between consecutive fragments
     const int mrow = m0 + wm * FM * fld + fr, ncol = n0 + wn * WN + fq * 4;
     // clamped coordinates for the loads of the pointer form; BUF: byte offsets, out of range where the lane is outside the matrix
     auto col = [&](int i) { const int n = ncol + i * 16; return n < p.N ? n : p.N - 4; };       // N % 4 == 0
@@ -347,7 +351,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
             const int b = mg / p.gn_rows, rem = mg - b * p.gn_rows;
             // granule id within the image: 32 consecutive rows, or (patch tiles) two 16-pixel runs one image row apart -- any one-to-one numbering
             // of an image's rows / 32 granules serves: the consumer only sums over them
-            const int chunk = p.gn_chunk0 + (p.frag_ld ? ((rem / p.frag_ld) >> 1) * (p.frag_ld >> 4) + ((rem % p.frag_ld) >> 4) : rem >> 5);
+            const int chunk = p.gn_chunk0 + (PATCH ? ((rem / p.frag_ld) >> 1) * (p.frag_ld >> 4) + ((rem % p.frag_ld) >> 4) : rem >> 5);
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 // 16 rows: four DPP adds (xor 1, xor 2, mirror in 8, mirror in 16) leave the row-of-16 total in every lane, VALU only;

@@ -172,9 +172,13 @@ __global__ __launch_bounds__(NW * 64) void gemm3x8_kernel(GemmArgs p) {
         if (nsplit > 1 && !splitk_reduce<FM, FN, NW>(p, acc, tile_all, slice, tid, smx)) return;
     }
     if constexpr (FM * FN > 16) {
-#pragma unroll
-        for (int c = 0; c < FN / 2; ++c)
-            epilogue<FM, 2, WM, WN, true>(p, reinterpret_cast<f32x4(&)[2][FM]>(acc[2 * c]), m0, n0 + 32 * c, wm, wn, lane);
+        // column chunks of two fragments, the chunk index a COMPILE-TIME constant: as a `#pragma unroll` loop the two huge inlined bodies exceed the
+        // pragma-unroll threshold as soon as the epilogue grows by a few instructions, the loop stays rolled, acc[2 * c] becomes a runtime index and the
+        // whole accumulator array moves to scratch -- K loop included (round 4: FF1 on tile 64 went from 55 to 87 us that way)
+        static_for([&](auto cc) {
+            constexpr int C = decltype(cc)::value;
+            epilogue<FM, 2, WM, WN, true>(p, reinterpret_cast<f32x4(&)[2][FM]>(acc[2 * C]), m0, n0 + 32 * C, wm, wn, lane);
+        }, std::make_integer_sequence<int, FN / 2>{});
         if constexpr (FN & 1)
             epilogue<FM, 1, WM, WN, true>(p, reinterpret_cast<f32x4(&)[1][FM]>(acc[FN - 1]), m0, n0 + 16 * (FN - 1), wm, wn, lane);
     } else {
