@@ -233,44 +233,89 @@ def pmc_traffic(kernel, m, n, k, path=None):
         return None, None
 
 
-def time_dominant_kernel(pipe, nb, iters=20):
-    """The single kernel with the largest share of device time (profiles/r02_per_edit_kernels.md): the GEMM on the UNet's
-    32x32-latent FF1 projection (M = nb*1024 tokens, N = 10240, K = 1280, bias + GEGLU epilogue).  Average launch duration by
-    HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K.  `traffic` is NOT measured here (PMC counters cannot be
-    collected inside the bench): it is read from profiles/dominant_kernel_pmc.json, which names the rocprofv3 --pmc CSVs it
-    was derived from, and is reported only when that record is for this shape."""
+def class_table(path=None):
+    """The "By class" rows of the committed per-shape in-situ profile (tools/shape_profile.py under rocprofv3 --kernel-trace: one eager single-stream
+    edit of this workload, launch log paired with the trace): launches, kernel ms and aggregate rate per kernel class, largest first.  Read from
+    profiles/, never measured here (a kernel trace cannot be taken inside the bench); the source file is named beside it."""
+    path = path or os.path.join(ROOT, "profiles", "r04_per_shape_roofline.md")
+    rows = []
+    try:
+        with open(path) as f:
+            lines = f.read().split("\n")
+        i = lines.index("## By class")
+        for l in lines[i + 4:]:
+            c = [x.strip() for x in l.strip().strip("|").split("|")]
+            if len(c) < 5 or not c[1].isdigit():
+                break
+            if c[0].startswith("_Z"):
+                continue
+            rate = c[4].split()
+            frac = None
+            if len(rate) == 2 and rate[1] in ("TF/s", "GB/s"):
+                frac = round(float(rate[0]) / (PEAK_F16_DENSE_TFLOPS if rate[1] == "TF/s" else 8000.0), 4)
+            rows.append({"class": c[0], "launches": int(c[1]), "ms": float(c[2]), "pct": float(c[3]), "rate": c[4], "frac_of_bound": frac})
+    except (OSError, ValueError, IndexError):
+        return None, None
+    return rows[:8], os.path.relpath(path, ROOT)
+
+
+def time_rotating_gemm(pipe, m, n, k, geglu, residual, iters=24):
+    """One GEMM problem of the UNet as it runs INSIDE the network: the weight matrix rotates over enough copies (> 256 MB) that every launch streams
+    it from HBM, not from the Infinity Cache (a UNet evaluation streams 2.6 GB of weights: no layer finds its own in cache), activations warm.
+    Average launch duration by HIP events on the launch stream; algorithmic FLOPs = 2 M N K."""
     from fie_amd import hip
     ctx, dev = pipe.ctx, pipe.ctx.device
-    m, n, k = nb * 1024, 10240, 1280
     g = torch.Generator(device=dev).manual_seed(1)
     a = torch.randn((m, k), generator=g, device=dev, dtype=torch.float16)
+    copies = max(2, int(300e6 / (n * k * 2)) + 1)
     w8, ctx.w8 = ctx.w8, getattr(pipe, "weight_dtype", "f16") == "f8e4m3"       # the fp8 configuration times its own kernel
     try:
-        w = ctx.pack_linear(torch.randn((n, k), generator=g, device=dev, dtype=torch.float16) * k ** -0.5, geglu=True)
+        ws = [ctx.pack_linear(torch.randn((n, k), generator=g, device=dev, dtype=torch.float16) * k ** -0.5, geglu=geglu) for _ in range(copies)]
     finally:
         ctx.w8 = w8
     bias = torch.randn((n,), generator=g, device=dev, dtype=torch.float16)
-    a8w8 = isinstance(w, hip.W8) and ctx.a8 and w.stride(0) % 128 == 0       # fp8 configuration: e4m3 activations in, e4m3 (GEGLU) out, as in the network
+    a8w8 = isinstance(ws[0], hip.W8) and ctx.a8 and ws[0].stride(0) % 128 == 0       # fp8 configuration: e4m3 activations in (and e4m3 GEGLU out), as in the network
     if a8w8:
         a = ctx.quantize_f8(a)
-    out = torch.empty((m, n // 2), device=dev, dtype=torch.uint8 if a8w8 else torch.float16)
-    for _ in range(3):
-        ctx.gemm(a, w, n, out=out, bias=bias, act=hip.ACT_GEGLU, out_f8=a8w8)
+    nout = n // 2 if geglu else n
+    out8 = a8w8 and geglu
+    out = torch.empty((m, nout), device=dev, dtype=torch.uint8 if out8 else torch.float16)
+    res = torch.randn((m, nout), generator=g, device=dev, dtype=torch.float16) if residual else None
+    act = hip.ACT_GEGLU if geglu else hip.ACT_NONE
+
+    def launch(w):
+        ctx.gemm(a, w, n, out=out, bias=bias, act=act, residual=res, out_f8=out8)
+    for w in ws[:3]:
+        launch(w)
     kernel = hip.last_gemm_kernel()
+    iters = max(iters, copies)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        ctx.gemm(a, w, n, out=out, bias=bias, act=hip.ACT_GEGLU, out_f8=a8w8)
+    for i in range(iters):
+        launch(ws[i % copies])
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     tf = 2.0 * m * n * k / (us * 1e-6) / 1e12
-    traffic_mb, traffic_src = pmc_traffic(kernel, m, n, k)
-    return {"kernel": f"{kernel} (FF1 GEGLU projection, 32x32 latents)", "shape": {"M": m, "N": n, "K": k},
-            "avg_us": round(us, 2), "launches": iters, "achieved": round(tf, 1), "frac": round(tf / PEAK_F16_DENSE_TFLOPS, 4),
-            "algorithmic_gflop_per_launch": round(2.0 * m * n * k / 1e9, 2),
-            "algorithmic_mb_per_launch": round((m * k + n * k + m * n // 2) * 2 / 1e6, 1),
-            "traffic_mb_per_launch": traffic_mb, "traffic_source": traffic_src}
+    return {"kernel": kernel, "shape": {"M": m, "N": n, "K": k}, "avg_us": round(us, 2), "launches": iters, "weight_copies": copies,
+            "achieved": round(tf, 1), "frac": round(tf / PEAK_F16_DENSE_TFLOPS, 4), "algorithmic_gflop_per_launch": round(2.0 * m * n * k / 1e9, 2),
+            "algorithmic_mb_per_launch": round((m * k + n * k + m * nout) * 2 / 1e6, 1)}
+
+
+def time_dominant_kernel(pipe, nb):
+    """The problem with the largest share of an edit's kernel time (top row of profiles/r04_per_shape_roofline.md): the GEMM of the UNet's
+    32x32-latent FF1 projection (M = nb * 1024 tokens, N = 10240, K = 1280, bias + GEGLU epilogue), timed as it runs in the network (cold weights:
+    time_rotating_gemm).  Beside it the largest problem of the kernel FAMILY with the largest share (the M = 2048 x N = 1280 projections on the small
+    ring tiles): the FF2 projection, K = 5120, + residual.  `traffic` is NOT measured here (PMC counters cannot be collected inside the bench): it is
+    read from profiles/dominant_kernel_pmc.json, which names the rocprofv3 --pmc CSVs it was derived from, and is reported only when that record is
+    for this shape and the tile the run used."""
+    m = nb * 1024
+    ff1 = time_rotating_gemm(pipe, m, 10240, 1280, geglu=True, residual=False)
+    ff2 = time_rotating_gemm(pipe, m, 1280, 5120, geglu=False, residual=True)
+    ff1["kernel"] += " (FF1 GEGLU projection, 32x32 latents)"
+    ff2["kernel"] += " (FF2 projection + residual, 32x32 latents)"
+    ff1["traffic_mb_per_launch"], ff1["traffic_source"] = pmc_traffic(ff1["kernel"], m, 10240, 1280)
+    return ff1, ff2
 
 
 def self_launch(args):
@@ -463,7 +508,8 @@ def main():
         for k, v in pipe.stage_ms().items():
             stage[k] = stage.get(k, 0.0) + v / 2
     pipe.timing = None
-    dominant = time_dominant_kernel(pipe, nb)
+    dominant, second = time_dominant_kernel(pipe, nb)
+    classes, classes_src = class_table()
     fl = flops.image_flops(cfgs, evals, nb)
     stage_graphs = stage_graph_ms(pipe, job0, fl) if not args.no_graph else {}
     log(f"stage graphs (single stream each): {stage_graphs}")
@@ -511,16 +557,22 @@ def main():
                        "unet_evals": evals, "cfg_batch": nb, "parallelism": f"image-parallel x{world}",
                        "launch": "eager" if args.no_graph else "hipGraph replay", "weights": args.weights,
                        "tflop_per_image": round(fl["total"] / 1e12, 2)},
-            # the dominant kernel (largest share of device time in profiles/), HIP-event timed above; the whole UNet forward
-            # (every launch between the events bracketing unet.encode + unet.decode, alone on one stream) is priced beside it
+            # the dominant problem (top row of profiles/r04_per_shape_roofline.md), HIP-event timed above on cold weights; the second kernel,
+            # the per-class table of the committed kernel trace and the whole UNet forward (every launch between the events bracketing
+            # unet.encode + unet.decode, alone on one stream, replayed from a hipGraph) are priced beside it
             "roofline": {"bound": "mfma", "kernel": dominant["kernel"], "shape": dominant["shape"],
                          "achieved": dominant["achieved"], "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": dominant["frac"], "traffic": dominant["traffic_mb_per_launch"],
                          "traffic_unit": "MB/launch, fabric side: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes",
                          "traffic_source": dominant["traffic_source"],
-                         "avg_us": dominant["avg_us"], "launches": dominant["launches"],
+                         "avg_us": dominant["avg_us"], "launches": dominant["launches"], "weight_copies": dominant["weight_copies"],
+                         "avg_us_what": "HIP events on the launch stream, the weight matrix rotated over > 256 MB of copies: the in-network (cold-weight) duration",
                          "algorithmic_gflop_per_launch": dominant["algorithmic_gflop_per_launch"],
                          "algorithmic_mb_per_launch": dominant["algorithmic_mb_per_launch"],
+                         "second": second,
+                         "second_what": "largest problem of the kernel family with the largest share of device time (M = 2048 x N = 1280 projections on the small ring tiles)",
+                         "class_table": classes, "class_table_source": classes_src,
+                         "class_table_what": "kernel classes of one edit, largest first: launches, kernel ms, share, aggregate rate, fraction of the bound (2.5 PF MFMA / 8 TB/s HBM); from the committed rocprofv3 kernel trace, not measured in this run",
                          "unet_forward": {"what": f"{cfgs['unet']['name']}, batch {nb}, random inputs", "achieved": round(unet_tflops, 2),
                                           "frac": round(unet_tflops / PEAK_F16_DENSE_TFLOPS, 4),
                                           "algorithmic_tflop": round(fl["unet"] * nb / 1e12, 3), "ms": round(unet_ms_per_fwd, 3)}},

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(GemmArgs p) {
 // descriptors' range check), so the vmcnt immediates stay compile-time constants per (chunk kind, tap); after the one irregular event (the row
 // bias of another image) the wave drains completely, which is always safe.
 // The column tile of a block is fixed (the grid is a multiple of the column tiles): one weight stream and one bias vector per block.
-constexpr int K_FIRST = 0, K_MID = 1, K_LAST_F = 2, K_LAST_N = 3;      // chunk kinds: first (stores), middle, last with / without a next tile to prefetch
+constexpr int K_FIRST = 0, K_MID = 1, K_LAST_F = 2, K_LAST_N = 3, K_LASTREG_S = 4;      // chunk kinds: first (stores), middle, last with / without a next tile to prefetch, last nine-tap chunk in front of side steps
 constexpr int n2_w(int kind, int t) { return kind == K_LAST_N && t + 2 > 8 ? 0 : RWH; }
 constexpr int n2_h(int kind, int t) { return kind != K_LAST_N && t < HSLOTS ? 1 : 0; }
 // VAR (switches of v2): 2 = ST16: sixteen-byte stores (two fragments' halves exchanged by v_permlane16_swap: 8 stores per wave and tile, one per tap);
@@ -266,11 +266,11 @@ constexpr int n2_wait(int var, bool res, int kind, int t) {
 }
 static_assert(n2_tail(true, K_LAST_F, 8) == 0 && n2_tail(true, K_FIRST, 8) == 0 && n2_st(0, K_FIRST, 8) == 0, "tap 8 carries nothing behind its weights");
 
-template <bool RES, bool GN, bool RB, int VAR, bool STAMP>
+template <bool RES, bool GN, bool RB, int VAR, bool STAMP, bool SIDE = false>
 __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
     constexpr int FM = 4, FN = 4, WN = 64;
     constexpr bool ST16 = (VAR & 2) != 0, STM = (VAR & 4) != 0, IM = (VAR & 8) != 0;
-    static_assert(!RES || true, "");
+    static_assert(!(SIDE && (RES || RB)), "1x1 side inputs belong to a resnet's conv2 + shortcut: no residual, no row bias");
     extern __shared__ __attribute__((aligned(16))) half_t smem[];
     char* const lds = reinterpret_cast<char*>(smem);
 
@@ -313,6 +313,15 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
         const int hy = pl / HP, hx = pl - hy * HP;
         hq[i] = q < HPIECES && pl < HP * HP ? (unsigned)((hy << 8) | hx) : 0xFF00u;
     }
+    auto halo_off_px = [&](int i, int img, int y0, int x0, unsigned pix_bytes) -> unsigned {      // the same pixel of an image whose pixels are pix_bytes apart (a 1x1 side input)
+        unsigned t = hq[i];
+        asm volatile("" : "+v"(t));
+        const int hy = (int)(t >> 8), hx = (int)(t & 255u);
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const bool ok = hy < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const unsigned chunk = (unsigned)((lane & 7) ^ (hx & 7));
+        return ok ? ((unsigned)(img * p.H + iy) * (unsigned)p.W + (unsigned)ix) * pix_bytes + chunk * 16u : kOob;
+    };
     auto halo_off = [&](int i, int img, int y0, int x0) -> unsigned {
         unsigned t = hq[i];
         asm volatile("" : "+v"(t));
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
         for (int j = 0; j < FM; ++j) outp[i][j] = (u32x2){0u, 0u};
 
     unsigned seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;     // STAMP: [0] DMA / store issue, [1] reads, [2] wait + barrier, [3] MFMA, [4] barrier, [5] prologue, [6] flush, [7] tile-end math
-    unsigned kseg[4] = {0, 0, 0, 0};                           // STAMP: whole K-steps by chunk kind (first = stores, middle, last with / without prefetch)
+    unsigned kseg[5] = {0, 0, 0, 0, 0};                           // STAMP: whole K-steps by chunk kind (first = stores, middle, last with / without prefetch)
     auto stamp = [&](int i) {
         if constexpr (STAMP) {
             __builtin_amdgcn_sched_barrier(0);
@@ -393,6 +402,21 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
     if constexpr (STAMP) tprev = (unsigned)__builtin_amdgcn_s_memtime();
 
     const int nchunks = p.Cin / BK;                            // >= 2 (checked by the launcher)
+    // SIDE (fie_conv3x3_plus_nhwc_f16: a resnet's conv2 + its 1x1 shortcut as one GEMM): behind the nine-tap chunks, one K-step per 64 channels of the
+    // side inputs X2 | X3 (row m of [B*H*W, C] matrices = pixel m of NHWC images): the step reads the CENTRE tap of a halo loaded from the side image,
+    // its weights sit behind the taps in the packed rows.  A tile then has 9 n + m K-steps, so the ring position of its first K-step (sb) moves by
+    // m % 3 per tile and the stage indices become runtime values; a side step prefetches the WHOLE next halo (six slots) and drains (vmcnt(0)): the
+    // m <= 8 side steps of a tile run at the load path's pace, the 9 n regular ones as before
+    const int n2side = SIDE ? p.C2x / BK : 0, nside = SIDE ? (p.C2x + p.C3x) / BK : 0;
+    const int steps = 9 * nchunks + nside;
+    int sb = 0;
+    auto rot3 = [](int x) { return x % 3; };                 // (a scalar: tap + ring position)
+    const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A2, 0, SIDE ? (int)p.a2_bytes * live : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A3, 0, SIDE ? (int)p.a3_bytes * live : 0, 0x00020000);
+    auto w_soff = [&](int s) -> unsigned {                   // byte offset of tile-local K-step s in a packed weight row
+        if (s < 9 * nchunks) { const int c = s / 9, t = s - 9 * c; return (unsigned)t * cin2 + (unsigned)c * (BK * 2); }
+        return 9u * cin2 + (unsigned)(s - 9 * nchunks) * (BK * 2);
+    };
     int tile = bid, m0 = 0, img = 0, y0 = 0, x0 = 0, img_rb = -1;
     geom(tile, m0, img, y0, x0);
     // the bias has landed before anything else is in flight (its registers are read at every tile end)
@@ -415,24 +439,33 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
     f16x8 fw[2][FN], fa[2][FM];
     // NEXT = the tile whose first halo the last chunk prefetches (its geometry in imgn / y0n / x0n); other chunks prefetch this tile's chunk c + 1 from h_off
     int imgn = 0, y0n = 0, x0n = 0;
+    bool have_next_ = false;
     auto kstep = [&](auto kindc, auto tapc, int c, unsigned hb, int hpf_buf) {
         constexpr int KIND = decltype(kindc)::value;
         constexpr int T = decltype(tapc)::value;
         constexpr int KY = T / 3, KX = T % 3;
-        constexpr int STAGE = T % STH, FILL = (T + 2) % STH;
+        const int STAGE = SIDE ? rot3(T + sb) : T % STH, FILL = SIDE ? rot3(T + 2 + sb) : (T + 2) % STH;
         const unsigned tk0 = tprev;
         // ---- what this K-step issues besides its fragment reads: weights of K-step kt + 2 (two pieces), a halo piece, deferred stores, residual loads.
         // In the load segment (default), or -- IM -- from inside the MFMA segment, one instruction behind every fourth MFMA: a vector-memory
         // instruction costs ~60 cycles of issue among MFMAs against 100-200 in a load segment that also reads 16 fragments (MI355X_MICROARCH.md,
         // cycle constants), and the load segment is what the MFMA segment of the other wave group waits for
         auto issue_wp = [&](int i) {
-            constexpr int T2 = (T + 2) % 9;
-            const int c2 = T + 2 > 8 ? (KIND >= K_LAST_F ? 0 : c + 1) : c;
-            bload16(rs_w, reinterpret_cast<half_t*>(lds + WRING_OFF + FILL * WSTAGE_B + (wave + 8 * i) * 1024), w_base + (unsigned)i * w_step,
-                    (unsigned)T2 * cin2 + (unsigned)c2 * (BK * 2));
+            if constexpr (SIDE && KIND == K_LASTREG_S) {         // K-step kt + 2 may be a side step, the next tile's first step, or nothing: then a real load into the dump (the counts stay exact)
+                int s2 = c * 9 + T + 2;
+                bool ok = true;
+                if (s2 >= steps) { s2 -= steps; ok = have_next_; }
+                bload16(rs_w, reinterpret_cast<half_t*>(lds + (ok ? WRING_OFF + FILL * WSTAGE_B + (wave + 8 * i) * 1024 : DUMP_OFF)), w_base + (unsigned)i * w_step, ok ? w_soff(s2) : 0u);
+            } else {
+                constexpr int T2 = (T + 2) % 9;
+                const int c2 = T + 2 > 8 ? ((KIND == K_LAST_F || KIND == K_LAST_N) ? 0 : c + 1) : c;
+                bload16(rs_w, reinterpret_cast<half_t*>(lds + WRING_OFF + FILL * WSTAGE_B + (wave + 8 * i) * 1024), w_base + (unsigned)i * w_step,
+                        (unsigned)T2 * cin2 + (unsigned)c2 * (BK * 2));
+            }
         };
         auto issue_h = [&]() {
-            if constexpr (KIND == K_LAST_F) bload16(rs_a, halo_dst(T, hpf_buf), halo_off(T, imgn, y0n, x0n), 0u);      // the next tile's first halo: offsets computed at use from the packed slot register
+            if constexpr (SIDE && KIND == K_LASTREG_S) bload16(rs_x2, halo_dst(T, hpf_buf), halo_off_px(T, img, y0, x0, (unsigned)p.lda2 * 2u), 0u);       // the first side chunk's patch
+            else if constexpr (KIND == K_LAST_F) bload16(rs_a, halo_dst(T, hpf_buf), halo_off(T, imgn, y0n, x0n), 0u);      // the next tile's first halo: offsets computed at use from the packed slot register
             else bload16(rs_a, halo_dst(T, hpf_buf), halo_off(T, img, y0, x0), (unsigned)(c + 1) * (BK * 2));        // this tile's next chunk
         };
         auto store1 = [&](int s) {
@@ -453,7 +486,7 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
             outp[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, rr_cur + (unsigned)j * r_jstep + (unsigned)(i * 32), 0, 0);
         };
         constexpr int NW_ = n2_w(KIND, T), NH_ = n2_h(KIND, T), NS_ = n2_st(VAR, KIND, T);
-        constexpr bool RLT = RES && KIND >= K_LAST_F && T == 8;
+        constexpr bool RLT = RES && (KIND == K_LAST_F || KIND == K_LAST_N) && T == 8;
         // slot g (0..7) of the MFMA segment: the instruction issued behind MFMA group g (IM), or everything at once in the load segment
         auto slot = [&](auto gc) {
             constexpr int Gs = decltype(gc)::value;
@@ -512,6 +545,63 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
         kstep(kindc, std::integral_constant<int, 6>{}, c, hb, hpf_buf);
         kstep(kindc, std::integral_constant<int, 7>{}, c, hb, hpf_buf);
         kstep(kindc, std::integral_constant<int, 8>{}, c, hb, hpf_buf);
+    };
+
+    // ---- one side K-step (SIDE): chunk e of [X2 | X3], centre tap; prefetches the whole next halo (side chunk e + 1, or the next tile's first chunk) and
+    // the weights of step + 2, then drains: every count behind it starts from zero
+    auto side_step = [&](int e, unsigned hb, int hpf_buf) {
+        const int s = 9 * nchunks + e;
+        const int stage = (e + sb) % 3, fill = (e + 2 + sb) % 3;
+        {
+            int s2 = s + 2;
+            bool ok = true;
+            if (s2 >= steps) { s2 -= steps; ok = have_next_; }
+            if (ok) {
+                const unsigned so = w_soff(s2);
+#pragma unroll
+                for (int i = 0; i < RWH; ++i)
+                    bload16(rs_w, reinterpret_cast<half_t*>(lds + WRING_OFF + fill * WSTAGE_B + (wave + 8 * i) * 1024), w_base + (unsigned)i * w_step, so);
+            }
+        }
+        if (e + 1 < nside) {
+            const bool x2 = e + 1 < n2side;
+            const unsigned pix = (unsigned)(x2 ? p.lda2 : p.lda3) * 2u, so = (unsigned)(x2 ? e + 1 : e + 1 - n2side) * (BK * 2);
+#pragma unroll
+            for (int i = 0; i < HSLOTS; ++i) {
+                if (x2) bload16(rs_x2, halo_dst(i, hpf_buf), halo_off_px(i, img, y0, x0, pix), so);
+                else bload16(rs_x3, halo_dst(i, hpf_buf), halo_off_px(i, img, y0, x0, pix), so);
+            }
+        } else if (have_next_) {
+#pragma unroll
+            for (int i = 0; i < HSLOTS; ++i) bload16(rs_a, halo_dst(i, hpf_buf), halo_off(i, imgn, y0n, x0n), 0u);
+        }
+        stamp(0);
+        const char* const hal = lds + HALO_OFF + hb;
+        const char* const wst = lds + WRING_OFF + stage * WSTAGE_B;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i) fw[kh][i] = *reinterpret_cast<const f16x8*>(wst + w_rd[kh] + i * 16 * 128);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) fa[kh][j] = *reinterpret_cast<const f16x8*>(hal + a_rd[1][kh] + (j + 1) * HP * 128);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(1);
+        wait_vm_barrier<0>();
+        stamp(2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kh][i], fa[kh][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(3);
+        __builtin_amdgcn_s_barrier();
+        stamp(4);
     };
 
     // ---- end of a tile: bias, row bias, activation, scale, residual on the accumulators (the order of gemm_common.h's epilogue); GroupNorm sums of
@@ -622,6 +712,7 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
     for (;;) {
         const int next = tile + G;
         const bool have_next = next < ntiles;
+        have_next_ = have_next;
         int m0n = 0;
         if (have_next) geom(next, m0n, imgn, y0n, x0n);
         if constexpr (RB) {
@@ -645,9 +736,16 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
         first_tile = false;
         ++g;
         for (int c = 1; c + 1 < nchunks; ++c, ++g) chunk(std::integral_constant<int, K_MID>{}, c, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
-        if (have_next) chunk(std::integral_constant<int, K_LAST_F>{}, nchunks - 1, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
-        else chunk(std::integral_constant<int, K_LAST_N>{}, nchunks - 1, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
-        ++g;
+        if constexpr (SIDE) {
+            chunk(std::integral_constant<int, K_LASTREG_S>{}, nchunks - 1, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
+            ++g;
+            for (int e = 0; e < nside; ++e, ++g) side_step(e, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
+            sb = (sb + nside) % 3;                               // the 9 n regular steps leave the ring position alone
+        } else {
+            if (have_next) chunk(std::integral_constant<int, K_LAST_F>{}, nchunks - 1, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
+            else chunk(std::integral_constant<int, K_LAST_N>{}, nchunks - 1, (g & 1) ? (unsigned)HALO_B : 0u, (g + 1) & 1);
+            ++g;
+        }
         tile_end(m0, img);
         ro_prev = ST16 ? row_off16(m0, p.ldc) : row_off(m0, p.ldc);
         stamp(7);
@@ -705,6 +803,8 @@ int fie_conv_halo_init(void) {
     if (e == hipSuccess) e = halo2_attr<false, false, true, 0, false>();
     if (e == hipSuccess) e = halo2_attr<false, true, true, 0, false>();
     if (e == hipSuccess) e = halo2_attr<false, false, false, 6, true>();
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo2_kernel<false, false, false, 6, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo2_kernel<false, true, false, 6, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo);
     if (e == hipSuccess) e = halo2_attr<true, true, false, 6, true>();
     if (e != hipSuccess) {
         fie_set_error("conv_halo: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -716,8 +816,13 @@ int fie_conv_halo_init(void) {
 // Shapes the halo-resident kernel takes: the plain same-size conv (stride 1, zero padding 1, no up-sampling gather, no 1x1 side inputs, fp16
 // weights) on maps whose height and width are multiples of 16, Cin % 64 == 0, operands the 32-bit buffer offsets reach (checked by the caller: dma_ok)
 bool fie_conv_halo_ok(const GemmArgs& a) {
-    return a.stride == 1 && !a.ups && !a.taps2 && !a.oscat && !a.A2 && !a.A3 && a.pt == 1 && a.pl == 1 && a.H == a.OH && a.W == a.OW && a.OH % 16 == 0 &&
-           a.OW % 16 == 0 && a.Cin % BK == 0 && a.Cin >= BK && !a.w_scale && a.K == 9 * a.Cin && !a.out_f8 && a.splitk <= 1;
+    const bool base = a.stride == 1 && !a.ups && !a.taps2 && !a.oscat && a.pt == 1 && a.pl == 1 && a.H == a.OH && a.W == a.OW && a.OH % 16 == 0 &&
+                      a.OW % 16 == 0 && a.Cin % BK == 0 && a.Cin >= BK && !a.w_scale && !a.out_f8 && a.splitk <= 1;
+    if (!base) return false;
+    if (!a.A2) return !a.A3 && a.K == 9 * a.Cin;
+    // 1x1 side inputs (conv2 + shortcut): the persistent form only, so everything that form asks for
+    return a.C2x % BK == 0 && a.C3x % BK == 0 && a.C2x > 0 && (a.A3 != nullptr) == (a.C3x > 0) && a.K == 9 * a.Cin + a.C2x + a.C3x && a.Cin >= 2 * BK && a.N % BNH == 0 &&
+           !a.res && !a.rowbias && a.act == FIE_ACT_NONE && a.scale == 1.f && a.lda2 * 2 * (int64_t)a.OW * a.OH < (1ll << 31) && a.lda3 * 2 * (int64_t)a.OW * a.OH < (1ll << 31);
 }
 
 // variant: 0 = v1 (one tile per block, code 71), 1 = v1 with stamps (73), 2 = v2: persistent blocks, deferred 16-byte stores issued inside the MFMA
@@ -731,11 +836,13 @@ int fie_launch_conv_halo(fie_ctx* ctx, GemmArgs& a, int variant) {
     a.nbn = (a.N + BNH - 1) / BNH;
     a.nbm = (a.M / (a.OH * a.OW)) * (a.OH >> 4) * (a.OW >> 4);
     const int tiles = a.nbm * a.nbn;
-    if (variant >= 2 && tiles <= ctx->num_cus) variant = variant == 4 ? 1 : 0;      // one tile per block: the one-tile form (its epilogue is shorter than a tile end + a flush)
+    const bool side = a.A2 != nullptr;
+    FIE_REQUIRE(!(side && variant != 2), "halo-resident conv: 1x1 side inputs run on tile code 72 only");
+    if (!side && variant >= 2 && tiles <= ctx->num_cus) variant = variant == 4 ? 1 : 0;      // one tile per block: the one-tile form (its epilogue is shorter than a tile end + a flush)
     // v2 stores during the first chunk and loads residuals in the last: two chunks at least; whole 128-channel column tiles (a wave whose channels lie
     // past N would issue stores / loads that the range check drops whole, and those do not keep the vmcnt order the counted waits rely on); row bias and
     // residual never come together (resnet conv1 / conv2); no activation / scale
-    if (variant >= 2 && (a.Cin < 2 * BK || a.N % BNH != 0 || (a.rowbias && a.res) || (variant == 4 && a.rowbias) || a.act != FIE_ACT_NONE || a.scale != 1.f)) variant = variant == 4 ? 1 : 0;
+    if (!side && variant >= 2 && (a.Cin < 2 * BK || a.N % BNH != 0 || (a.rowbias && a.res) || (variant == 4 && a.rowbias) || a.act != FIE_ACT_NONE || a.scale != 1.f)) variant = variant == 4 ? 1 : 0;
     if (variant < 2) {
         const dim3 grid((unsigned)tiles);
         if (variant == 1) fie_launch(ctx, (conv_halo_kernel<true>), grid, dim3(512), kLdsHalo, a);
@@ -760,7 +867,8 @@ int fie_launch_conv_halo(fie_ctx* ctx, GemmArgs& a, int variant) {
         else if (gn) FIE_HALO2(false, true, false, VAR, false);                            \
         else FIE_HALO2(false, false, false, VAR, false);                                   \
     } while (0)
-    if (variant == 4) { if (res || gn) FIE_HALO2(true, true, false, 6, true); else FIE_HALO2(false, false, false, 6, true); }
+    if (side) { if (gn) fie_launch(ctx, (conv_halo2_kernel<false, true, false, 6, false, true>), grid, dim3(512), kLdsHalo, a); else fie_launch(ctx, (conv_halo2_kernel<false, false, false, 6, false, true>), grid, dim3(512), kLdsHalo, a); }
+    else if (variant == 4) { if (res || gn) FIE_HALO2(true, true, false, 6, true); else FIE_HALO2(false, false, false, 6, true); }
     else if (variant == 5) FIE_HALO2_V(0);
     else FIE_HALO2_V(6);
 #undef FIE_HALO2_V

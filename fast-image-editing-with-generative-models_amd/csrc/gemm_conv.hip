@@ -591,7 +591,7 @@ int heuristic_code(const fie_ctx* ctx, const GemmArgs& a, bool dma_ok) {
     int code;
     if (!dma_ok) {
         code = b42 >= cus ? 2 : 3;
-    } else if (MODE == 1 && fie_conv_halo_ok(a) && 4 * (int64_t)(a.M / 256) * ((a.N + 127) / 128) >= 3 * cus &&
+    } else if (MODE == 1 && fie_conv_halo_ok(a) && 4 * (int64_t)(a.M / 256) * ((a.N + 127) / 128) >= 3 * cus && a.C2x + a.C3x <= 4 * BK &&      // (1x1 side inputs: each 64 channels cost a drained K-step: the rule takes few of them, the tuner may take more)
                std::find(std::begin(ctx->tune_exclude), std::end(ctx->tune_exclude), 72) == std::end(ctx->tune_exclude)) {      // fie_debug_tune_exclude("72"): the A/B switch
         // stride-1 same-size convs on maps of whole 16x16 patches with enough (patch, 128-channel) tiles to fill the chip: the halo-resident kernel
         // (conv_halo.hip; persistent, deferred stores).  Measured against every im2col code on the VAE's and the UNet's 64x64 / 128x128-latent
@@ -648,7 +648,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     FIE_REQUIRE(t != nullptr, "unknown tile code %d", code);
     FIE_REQUIRE(code < 40 || dma_ok, "tile code %d: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)", code);
     FIE_REQUIRE(!(a.taps2 && (code < 40 || a.w_scale)), "tile code %d: the 2x2 parity convs run on the f16 LDS-DMA kernels only", code);
-    FIE_REQUIRE(!(MODE == 1 && a.A2 && (code < 40 || code == 81 || code == 82 || a.w_scale)), "tile code %d: conv + 1x1 side inputs run on the f16 ring kernels only", code);
+    FIE_REQUIRE(!(MODE == 1 && a.A2 && (code < 40 || code == 81 || code == 82 || a.w_scale)), "tile code %d: conv + 1x1 side inputs run on the f16 ring kernels and the halo-resident kernel (72) only", code);
     FIE_REQUIRE(!((code >= 71 && code <= 76) && (MODE != 1 || !dma_ok || !fie_conv_halo_ok(a))), "tile code %d (halo-resident conv): stride-1 same-size 3x3 conv with H, W %% 16 == 0, Cin %% 64 == 0, f16 weights only", code);
     if (order < 0) {
         // Tile order = which operand an XCD re-streams past its 4 MiB L2.  Consecutive tile ids run on one XCD (xcd_remap), so an

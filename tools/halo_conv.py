@@ -63,6 +63,72 @@ def check(code=71):
     print("correctness ok", flush=True)
 
 
+def check_plus(code=72):
+    """conv3x3(x) + [x2 | x3] W1x1^T (fie_conv3x3_plus_nhwc_f16: a resnet's conv2 + its 1x1 shortcut) on the halo-resident kernel against torch and against the
+    ring kernels; repeats bit-identical."""
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for b, h, w, cin, cout, c2, c3, gn in [(1, 64, 64, 128, 128, 256, 0, False), (2, 64, 96, 256, 256, 128, 64, True), (1, 320, 320, 128, 128, 256, 0, True),
+                                            (2, 64, 64, 640, 640, 1280, 640, True), (1, 1024, 1024, 128, 128, 256, 0, True)]:
+        x = torch.randn(b, h, w, cin, generator=g, device=DEV, dtype=torch.float16)
+        x2 = torch.randn(b * h * w, c2, generator=g, device=DEV, dtype=torch.float16)
+        x3 = torch.randn(b * h * w, c3, generator=g, device=DEV, dtype=torch.float16) if c3 else None
+        wt = torch.randn(cout, cin, 3, 3, generator=g, device=DEV, dtype=torch.float16) * (9 * cin) ** -0.5
+        w1 = torch.randn(cout, c2 + c3, generator=g, device=DEV, dtype=torch.float16) * (c2 + c3) ** -0.5
+        bias = torch.randn(cout, generator=g, device=DEV, dtype=torch.float16)
+        wc = ctx.pack_conv3x3(wt)
+        wplus = torch.cat([wc[:, :9 * cin], ctx.pack_linear(w1)[:, :c2 + c3]], 1).contiguous()
+        side = x2 if x3 is None else torch.cat([x2, x3], 1)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float(), bias.float(), padding=1) + (side.float() @ w1.float().T).view(b, h, w, cout).permute(0, 3, 1, 2)
+        ctx.force_tile(code)
+        outs = [ctx.conv3x3_plus(x, wplus, cout, x2, x3, bias=bias, gn_groups=32 if gn else None) for _ in range(5)]
+        name = hip.last_gemm_kernel(ctx)
+        assert "conv_halo2" in name, name
+        torch.cuda.synchronize()
+        err = ((outs[0].float().permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max()).item()
+        same = all(torch.equal(o, outs[0]) for o in outs[1:])
+        ctx.force_tile(0)
+        extra = ""
+        if gn:
+            gam, bet = torch.ones(cout, device=DEV, dtype=torch.float16), torch.zeros(cout, device=DEV, dtype=torch.float16)
+            gnv = ctx.groupnorm(outs[-1], gam, bet, 32, 1e-5, True)
+            gref = F.silu(F.group_norm(outs[-1].float().permute(0, 3, 1, 2), 32, eps=1e-5))
+            extra = f", GroupNorm from its sums {((gnv.float().permute(0, 3, 1, 2) - gref).abs().max() / gref.abs().max()).item():.2e}"
+        print(f"check +1x1 code {code} B={b} {h}x{w} {cin}->{cout} side {c2}+{c3}: rel err {err:.2e}, repeats identical: {same}{extra}", flush=True)
+        assert err < 4e-3 and same
+
+
+def bench_plus(codes):
+    for b, h, cin, cout, c2, c3 in [(1, 1024, 128, 128, 256, 0), (1, 512, 256, 256, 512, 0), (1, 512, 256, 256, 128, 0), (1, 256, 512, 512, 256, 0), (2, 64, 640, 640, 1280, 640), (2, 64, 640, 640, 640, 640)]:
+        copies = max(2, min(6, int(600e6 / (b * h * h * cin * 2)) + 1))
+        xs = [torch.randn(b, h, h, cin, device=DEV, dtype=torch.float16) for _ in range(copies)]
+        x2 = torch.randn(b * h * h, c2, device=DEV, dtype=torch.float16)
+        x3 = torch.randn(b * h * h, c3, device=DEV, dtype=torch.float16) if c3 else None
+        wc = ctx.pack_conv3x3(torch.randn(cout, cin, 3, 3, device=DEV, dtype=torch.float16) * (9 * cin) ** -0.5)
+        wplus = torch.cat([wc[:, :9 * cin], ctx.pack_linear(torch.randn(cout, c2 + c3, device=DEV, dtype=torch.float16) * 0.02)[:, :c2 + c3]], 1).contiguous()
+        bias = torch.randn(cout, device=DEV, dtype=torch.float16)
+        fns = [lambda x=x: ctx.conv3x3_plus(x, wplus, cout, x2, x3, bias=bias, gn_groups=32) for x in xs]
+        flops = 2.0 * b * h * h * cout * (cin * 9 + c2 + c3)
+        times = {c: [] for c in codes}
+        ok = {}
+        for c in codes:
+            ctx.force_tile(c)
+            try:
+                fns[0]()
+                ok[c] = True
+            except hip.FieError:
+                ok[c] = False
+        torch.cuda.synchronize()
+        iters = max(4, min(40, int(0.02 / (flops / 0.8e15))))
+        for _ in range(5):
+            for c in codes:
+                if ok[c]:
+                    ctx.force_tile(c)
+                    times[c].append(time_rot(fns, iters))
+        ctx.force_tile(0)
+        cells = [f"{c}: n/a" if not ok[c] else f"{c}: {statistics.median(times[c]) * 1e6:7.1f} us {flops / statistics.median(times[c]) / 1e12:6.0f} TF/s" for c in codes]
+        print(f"conv+1x1 B={b} {h}x{h} {cin}->{cout} side {c2}+{c3}  " + "  ".join(cells), flush=True)
+
+
 def time_rot(fns, iters):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -153,6 +219,10 @@ if __name__ == "__main__":
     for c in codes:
         if 71 <= c <= 76:
             check(c)
+    if "--plus" in sys.argv:
+        check_plus(72)
+        bench_plus([0, 72, 52, 96, 42])
+        sys.exit(0)
     if "--stamps" in sys.argv:
         stamps(shapes[:3], 73)
         stamps(shapes[:3], 74)
