@@ -1,8 +1,11 @@
 """The graph-level C-ABI forwards (include/fie.h: fie_*_forward_f16, csrc/graphs.cpp) driven from Python: what a non-Python host would do.
 
 `register_*` hands a model's packed weights to the library under their diffusers parameter names (fie_weights_register; the tensors stay owned
-by the Python objects), the `*_forward` functions call the C++ walks with raw tensor pointers.  The product path (pipe.py) does NOT use this
-module -- its Python walks take fusions the C++ walks do not -- tests/test_programs_gpu.py does, to pin the C++ walks against the Python ones."""
+by the Python objects), the `*_forward` functions call the C++ walks with raw tensor pointers.  The C++ walks take the same in-model fusions as
+the Python walks (GroupNorm sums from the producing epilogue, conv2 + 1x1 shortcut as one launch, 2x2-parity up-samplers); what only the
+product path (pipe.py) has is what needs state across calls or crosses two entries (the text K/V cached over the steps, the one-launch
+timestep embedding, zero-conv epilogues adding into the UNet's skips, the two-stream fork).  tests/test_cabi_graphs_gpu.py pins the C++ walks
+against the Python ones."""
 import ctypes
 
 import torch
@@ -32,6 +35,8 @@ class _Reg:
         self.raw(name + ".weight", c.wp, c.cout, c.wp.stride(0))
         if c.b is not None:
             self.vec(name + ".bias", c.b)
+        if getattr(c, "wp4", None) is not None and self.ctx.up2x_parity:          # an up-sampler's four 2x2 parity matrices: the walk takes that form
+            self.raw(name + ".weight4", c.wp4, c.wp4.shape[1], c.wp4.stride(1))
 
     def norm(self, name, nm):
         self.vec(name + ".weight", nm.g)
@@ -41,6 +46,9 @@ class _Reg:
         self.norm(p + "norm1", r.n1); self.conv(p + "conv1", r.c1); self.norm(p + "norm2", r.n2); self.conv(p + "conv2", r.c2)
         if r.sc is not None:
             self.lin(p + "conv_shortcut", r.sc)
+        if r.wp_plus is not None and self.ctx.conv_plus_shortcut:                  # conv2 + 1x1 shortcut as one launch
+            self.raw(p + "conv2_plus.weight", r.wp_plus, r.c2.n, r.wp_plus.stride(0))
+            self.vec(p + "conv2_plus.bias", r.b_plus)
 
 
 def _keep(obj, reg):

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(NWV * 64) void attn2_kernel(AttnArgs p) {
             for (int d = 0; d < DF; ++d) {
                 float x[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = fminf(fmaxf(o[a][d][r] * s8, -448.f), 448.f);
+                for (int r = 0; r < 4; ++r) x[r] = fie_sat448(o[a][d][r] * s8);
                 int pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], 0, false);
                 pk = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], pk, true);
                 *reinterpret_cast<int*>(orow8 + d * 16 + fq * 4) = pk;

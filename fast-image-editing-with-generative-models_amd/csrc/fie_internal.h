@@ -138,6 +138,12 @@ void fie_set_error(const char* fmt, ...);
 
 static inline int64_t fie_roundup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// value -> the e4m3 range, saturating: +-448 for finite inputs; a NaN stays a NaN and +-Inf becomes one (the conversion writes the e4m3 NaN code and
+// the consuming MFMA spreads it), so a numerical blow-up upstream stays as visible in the fp8 configuration as the fp16 path would leave it
+__device__ __forceinline__ float fie_sat448(float x) {
+    const float c = fminf(fmaxf(x, -448.f), 448.f);
+    return fabsf(x) <= 3.402823466e38f ? c : __builtin_nanf("");
+}
 __device__ __forceinline__ float fie_silu(float x) { return x / (1.0f + __expf(-x)); }
 // exact-erf GELU.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, three orders below fp16 resolution): one rcp, one
 // exp and five FMAs instead of libm's branchy erff -- the GEGLU epilogue evaluates it for every FF1 output element.

@@ -380,7 +380,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[FN][FM]
         if (p.out_f8) {                                     // e4m3 bytes for an fp8-activation consumer: 4 (GEGLU: 2) bytes per lane and fragment
             const __amdgpu_buffer_rsrc_t rs8 = rsrc(p.C, (int64_t)(p.M - 1) * p.ldc + (geglu ? p.N >> 1 : p.N));
             const float inv = p.out_inv_scale;
-            auto q = [&](float x) { return fminf(fmaxf(x * inv, -448.f), 448.f); };
+            auto q = [&](float x) { return fie_sat448(x * inv); };
 #pragma unroll
             for (int j = 0; j < FM; ++j) {
                 const int m = mrow + j * fld;

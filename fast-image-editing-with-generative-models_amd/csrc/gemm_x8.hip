@@ -230,7 +230,7 @@ __global__ void quant_f8_kernel(const half_t* x, int64_t ldx, unsigned char* y, 
         float v[8];
         fie_load8(x + r * ldx + c, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf(v[j] * inv, -448.f), 448.f);
+        for (int j = 0; j < 8; ++j) v[j] = fie_sat448(v[j] * inv);
         int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
         int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);

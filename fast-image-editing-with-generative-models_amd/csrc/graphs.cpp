@@ -17,10 +17,16 @@
 //        "...ff.net.0.proj" in the GEGLU layout of fie_pack_rows_f16 (value / gate rows interleaved, bias likewise)
 //        "post_quant_conv.weight"    the 4x4 1x1 conv zero-padded to 8x8 and packed as a linear; its bias padded to 8
 //
-// The walks mirror fie_amd/{clip,vae,nn}.py (same kernels, same order) except for fusions the Python walks take and these do not (GroupNorm
-// sums from the producing epilogue, 2x2-parity up-samplers, conv2 + 1x1 shortcut as one GEMM, the one-launch timestep embedding, zero-conv
-// epilogues adding straight into the UNet's skips), so outputs agree with the Python walks to rounding, not bit for bit
-// (tests/test_programs_gpu.py).  Activations live in ONE caller-provided workspace managed by a first-fit arena: every tensor is released
+//        fused matrices the host MAY register (the walk takes the fusion where it finds them, the plain sequence where not):
+//        "<resnet>conv2_plus.weight" / ".bias"   conv2's packed matrix with the 1x1 shortcut's columns appended, biases summed (fie_conv3x3_plus_nhwc_f16)
+//        "<upsampler conv>.weight4"              the four 2x2 parity matrices of fie_conv_up2x_nhwc_f16 (n = Npad, ld = ldw)
+//
+// The walks mirror fie_amd/{clip,vae,nn}.py (same kernels, same order) and take the same fusions inside a model: GroupNorm sums from the
+// producing epilogue (fie_gn_stats_target: every conv / projection whose output feeds a GroupNorm), conv2 + 1x1 shortcut as one launch, the
+// 2x2-parity up-samplers.  What they still do not take: the one-launch timestep embedding (needs a zeroed barrier workspace that outlives the
+// call), the cross-attention K/V of the step-invariant text cached ACROSS calls (an entry is stateless: it projects them per call), and the
+// zero-conv epilogues adding straight into the UNet's skips (two entries: the ControlNet returns its residuals as upstream does) -- so the
+// VAE walks agree with the Python ones bit for bit and the UNet / ControlNet ones to rounding (tests/test_cabi_graphs_gpu.py).  Activations live in ONE caller-provided workspace managed by a first-fit arena: every tensor is released
 // when its last reader has been issued (stream order makes the reuse safe), and fie_*_workspace_bytes replays the same allocation sequence
 // without launching to return the high-water mark.  Everything is asynchronous on the ctx stream and hipGraph-capturable like the op entries.
 #include <string>
@@ -65,6 +71,8 @@ struct T {                      // a [rows, c] f16 matrix (NHWC activations: row
     void* ext = nullptr;
     int64_t rows = 0;
     int c = 0;
+    int64_t gn_off = -1;        // GroupNorm partial sums its producer's epilogue left (arena offset), -1: none
+    int gn_pg = 0;              // slots per 32-row granule: the groups, or N / 4 quads (include/fie.h: fie_gn_stats_target)
     bool live() const { return off >= 0 || ext != nullptr; }
 };
 
@@ -75,6 +83,7 @@ struct Walk {
     char* base;
     Arena arena;
     int rc = FIE_OK;
+    bool plan_fused = true;     // plan mode: size the walk WITH the optional fused matrices (the entry takes the max of both plans)
     Walk(fie_ctx* c, const char* w, const char* pre, void* ws, int64_t cap) : ctx(c), who(w), prefix(pre ? pre : ""), base(static_cast<char*>(ws)), arena(cap) {}
     bool plan() const { return ctx == nullptr; }
     bool ok() const { return rc == FIE_OK; }
@@ -92,7 +101,29 @@ struct Walk {
         if (off < 0 && rc == FIE_OK) { fie_set_error("%s: workspace too small", who); rc = FIE_EINVAL; off = 0; }
         return off;
     }
-    void free(T& t) { if (t.off >= 0 && !t.ext) arena.give(t.off); t.off = -1; }
+    void free(T& t) {
+        if (t.off >= 0 && !t.ext) {
+            arena.give(t.off);
+            if (t.gn_off >= 0) arena.give(t.gn_off);           // a borrowed view (off < 0) leaves the sums to the owner
+        }
+        t.off = -1; t.gn_off = -1;
+    }
+    // an optional fused matrix: registered (run) / per the plan's flag
+    bool fused(const std::string& name) const { return plan() ? plan_fused : ctx->weights.find(prefix + name) != ctx->weights.end(); }
+    // Arms the NEXT launch to leave the GroupNorm partial sums of its [rows_total, n] output (include/fie.h: fie_gn_stats_target) where the group
+    // width allows -- the rule of fie_amd/hip.py::_gn_stats_arm: 4 / 8 / 16 channels per group, or 4-channel quads for the wider groups of maps
+    // with >= 4096 pixels (below that the single-pass GroupNorm is one launch anyway).  Call right before the producing launch.
+    void gn_arm(T& out, int n, int64_t rpi, int groups) {
+        if (groups <= 0 || n % groups || rpi % 32 || out.rows % rpi || out.c != n || out.ext) return;
+        int cg = n / groups, pg = groups;
+        if (cg != 4 && cg != 8 && cg != 16) {
+            if (cg % 4 || rpi < 4096) return;
+            pg = n / 4;
+        }
+        out.gn_off = scratch(fie_gn_stats_bytes((int)(out.rows / rpi), rpi, pg));
+        out.gn_pg = pg;
+        if (!plan() && ok()) run(fie_gn_stats_target(ctx, base + out.gn_off, rpi, pg));
+    }
     static T ext(const void* p, int64_t rows, int c) { T t; t.ext = const_cast<void*>(p); t.rows = rows; t.c = c; return t; }
     half_t* p(const T& t, int col = 0) const { return (t.ext ? static_cast<half_t*>(t.ext) : reinterpret_cast<half_t*>(base + t.off)) + col; }
 
@@ -120,13 +151,14 @@ struct Walk {
     // ---- op wrappers.  Every one allocates its output (or writes into `dst`) and leaves its inputs alone: the caller frees them.
     // out[m, n] = act(A W^T + bias + rowbias) * scale + residual; A = [a | a2]; (a_col0, a_cols): a column window of `a`
     T linear(const std::string& name, const T& a, int N, int act = FIE_ACT_NONE, const T* res = nullptr, float scale = 1.f, const T* a2 = nullptr,
-             const void* rowbias = nullptr, int64_t ld_rb = 0, int rpb = 0, const T* dst = nullptr, bool bias_optional = true) {
+             const void* rowbias = nullptr, int64_t ld_rb = 0, int rpb = 0, const T* dst = nullptr, bool bias_optional = true, int64_t gn_rpi = 0,
+             int gn_groups = 0) {
         const int nout = act == FIE_ACT_GEGLU ? N / 2 : N;
         T out = dst ? *dst : alloc(a.rows, nout);
-        if (plan() || !ok()) return out;
         const fie_weight* w = wt(name + ".weight", N);
         const void* b = vec(name + ".bias", bias_optional);
-        if (!w) return out;
+        if (gn_groups && !dst && (plan() || w)) gn_arm(out, N, gn_rpi, gn_groups);
+        if (plan() || !ok() || !w) return out;
         const int k1 = a.c, k = a.c + (a2 ? a2->c : 0);
         run(fie_gemm_f16(ctx, p(a), a.c, k1, a2 ? p(*a2) : nullptr, a2 ? a2->c : 0, w->ptr, w->ld, p(out), out.c, (int)a.rows, N, k, b, rowbias, ld_rb, rpb,
                          res ? p(*res) : nullptr, res ? res->c : 0, scale, act));
@@ -134,20 +166,47 @@ struct Walk {
     }
     // 3x3 conv over x = [B, H, W, x.c]; cout real output channels, the tensor is [B, OH, OW, ldc] with ldc = roundup(cout, 4)
     T conv(const std::string& name, const T& x, int B, int H, int W, int cout, int ups = 0, int stride = 1, int pad_mode = 0, int act = FIE_ACT_NONE,
-           const T* res = nullptr, const void* rowbias = nullptr, int64_t ld_rb = 0, const T* dst = nullptr) {
+           const T* res = nullptr, const void* rowbias = nullptr, int64_t ld_rb = 0, const T* dst = nullptr, int gn_groups = 0) {
         const int Hin = H << ups, Win = W << ups;
         const int OH = pad_mode == 1 ? (Hin + 1 - 3) / stride + 1 : (Hin + 2 - 3) / stride + 1, OW = pad_mode == 1 ? (Win + 1 - 3) / stride + 1 : (Win + 2 - 3) / stride + 1;
         const int n4 = (cout + 3) / 4 * 4;
         T out = dst ? *dst : alloc((int64_t)B * OH * OW, n4);
-        if (plan() || !ok()) return out;
         const fie_weight* w = wt(name + ".weight", cout);
         const void* b = vec(name + ".bias", true);
-        if (!w) return out;
+        if (gn_groups && !dst && n4 == cout && (plan() || w)) gn_arm(out, cout, (int64_t)OH * OW, gn_groups);
+        if (plan() || !ok() || !w) return out;
         run(fie_conv3x3_nhwc_f16(ctx, p(x), B, H, W, x.c, ups, stride, pad_mode, w->ptr, w->ld, p(out), out.c, n4, b, rowbias, ld_rb, res ? p(*res) : nullptr,
                                  res ? res->c : 0, 1.0f, act));
         return out;
     }
-    // GroupNorm (+ SiLU) over the channel concatenation [x | x2]
+    // conv3x3(x) + [x2 | x3] W1x1^T: a resnet's conv2 and its 1x1 shortcut as one launch (the host registered "<name>.weight" = conv2's packed
+    // matrix with the shortcut's columns appended, "<name>.bias" = the two biases summed)
+    T conv_plus(const std::string& name, const T& x, int B, int H, int W, int cout, const T& x2, const T* x3, int gn_groups) {
+        T out = alloc((int64_t)B * H * W, cout);
+        const fie_weight* w = wt(name + ".weight", cout);
+        const void* b = vec(name + ".bias", true);
+        if (gn_groups && (plan() || w)) gn_arm(out, cout, (int64_t)H * W, gn_groups);
+        if (plan() || !ok() || !w) return out;
+        run(fie_conv3x3_plus_nhwc_f16(ctx, p(x), B, H, W, x.c, w->ptr, w->ld, p(out), out.c, cout, b, nullptr, 0, 1.0f, FIE_ACT_NONE, p(x2), x2.c, x2.c,
+                                      x3 ? p(*x3) : nullptr, x3 ? x3->c : 0, x3 ? x3->c : 0));
+        return out;
+    }
+    // conv3x3(nearest-2x(x)) as four 2x2 parity convs ("<name>.weight4": the matrices of fie_amd/hip.py::pack_conv_up2x, n = Npad)
+    T conv_up2x(const std::string& name, const T& x, int B, int H, int W, int cout, int gn_groups) {
+        T out = alloc((int64_t)B * 4 * H * W, cout);
+        const fie_weight* w = wt(name + ".weight4");
+        const void* b = vec(name + ".bias", true);
+        if (gn_groups && (plan() || w)) gn_arm(out, cout, (int64_t)4 * H * W, gn_groups);
+        if (plan() || !ok() || !w) return out;
+        run(fie_conv_up2x_nhwc_f16(ctx, p(x), B, H, W, x.c, w->ptr, w->ld, (int)w->n, p(out), out.c, cout, b, nullptr, 0, 1.0f, FIE_ACT_NONE));
+        return out;
+    }
+    // the 2x up-sampler of a decoder level: the parity form where its matrices are registered, the nearest-2x gather of the 9-tap conv where not
+    T upsample_conv(const std::string& name, const T& x, int B, int H, int W, int cout, int gn_groups) {
+        if (x.c % 64 == 0 && cout % 4 == 0 && fused(name + ".weight4")) return conv_up2x(name, x, B, H, W, cout, gn_groups);
+        return conv(name, x, B, H, W, cout, 1, 1, 0, FIE_ACT_NONE, nullptr, nullptr, 0, nullptr, gn_groups);
+    }
+    // GroupNorm (+ SiLU) over the channel concatenation [x | x2]; a tensor that carries its producer's partial sums is read once instead of twice
     T gnorm(const std::string& name, const T& x, int B, int G, float eps, int silu, const T* x2 = nullptr) {
         const int64_t rpi = x.rows / B;
         T out = alloc(x.rows, x.c + (x2 ? x2->c : 0));
@@ -156,7 +215,10 @@ struct Walk {
         if (!plan() && ok()) {
             const void* g = vec(name + ".weight");
             const void* b = vec(name + ".bias");
-            if (g && b) run(fie_groupnorm_nhwc_f16(ctx, p(x), x.c, x2 ? p(*x2) : nullptr, x2 ? x2->c : 0, p(out), B, rpi, G, g, b, eps, silu, base + ws));
+            if (g && b && x.gn_off >= 0 && !x2)
+                run(fie_groupnorm_stats_nhwc_f16(ctx, p(x), x.c, p(out), B, rpi, G, g, b, eps, silu, base + x.gn_off, base + ws, x.gn_pg == G ? 0 : x.gn_pg));
+            else if (g && b)
+                run(fie_groupnorm_nhwc_f16(ctx, p(x), x.c, x2 ? p(*x2) : nullptr, x2 ? x2->c : 0, p(out), B, rpi, G, g, b, eps, silu, base + ws));
         }
         arena.give(ws);
         return out;
@@ -182,17 +244,19 @@ struct Walk {
 // ResnetBlock2D without a time embedding (upstream resnet.py): GN+SiLU -> conv1 -> GN+SiLU -> conv2 + (1x1 shortcut | identity).  Frees x.
 T vae_resnet(Walk& s, const std::string& p, T x, int H, int W, int cout, int G, float eps) {
     T y = s.gnorm(p + "norm1", x, 1, G, eps, 1);
-    T y1 = s.conv(p + "conv1", y, 1, H, W, cout);
+    T y1 = s.conv(p + "conv1", y, 1, H, W, cout, 0, 1, 0, FIE_ACT_NONE, nullptr, nullptr, 0, nullptr, G);     // norm2's sums ride on conv1's epilogue
     s.free(y);
     T y2 = s.gnorm(p + "norm2", y1, 1, G, eps, 1);
     s.free(y1);
-    T out;
-    if (x.c != cout) {
+    T out;                                                                                                    // ... and the next block's norm1 on conv2's
+    if (x.c != cout && x.c % 64 == 0 && cout % 64 == 0 && s.fused(p + "conv2_plus.weight")) {
+        out = s.conv_plus(p + "conv2_plus", y2, 1, H, W, cout, x, nullptr, G);
+    } else if (x.c != cout) {
         T sc = s.linear(p + "conv_shortcut", x, cout);
-        out = s.conv(p + "conv2", y2, 1, H, W, cout, 0, 1, 0, FIE_ACT_NONE, &sc);
+        out = s.conv(p + "conv2", y2, 1, H, W, cout, 0, 1, 0, FIE_ACT_NONE, &sc, nullptr, 0, nullptr, G);
         s.free(sc);
     } else {
-        out = s.conv(p + "conv2", y2, 1, H, W, cout, 0, 1, 0, FIE_ACT_NONE, &x);
+        out = s.conv(p + "conv2", y2, 1, H, W, cout, 0, 1, 0, FIE_ACT_NONE, &x, nullptr, 0, nullptr, G);
     }
     s.free(y2);
     s.free(x);
@@ -206,7 +270,7 @@ T vae_mid_attn(Walk& s, const std::string& p, T x, int G, float eps) {
     s.free(y);
     T a = s.attention(qkv, 0, qkv, c, qkv, 2 * c, 1, 1, c, (int)x.rows, (int)x.rows);
     s.free(qkv);
-    T o = s.linear(p + "to_out.0", a, c, FIE_ACT_NONE, &x);
+    T o = s.linear(p + "to_out.0", a, c, FIE_ACT_NONE, &x, 1.f, nullptr, nullptr, 0, 0, nullptr, true, x.rows, G);
     s.free(a);
     s.free(x);
     return o;
@@ -219,7 +283,7 @@ void vae_decode_walk(Walk& s, const fie_vae_config* cfg, const void* z, void* ou
     int H = h, W = w;
     T zin = Walk::ext(z, (int64_t)h * w, 8);
     T x0 = s.linear("post_quant_conv", zin, 8);
-    T x = s.conv("decoder.conv_in", x0, 1, H, W, ctop);
+    T x = s.conv("decoder.conv_in", x0, 1, H, W, ctop, 0, 1, 0, FIE_ACT_NONE, nullptr, nullptr, 0, nullptr, G);
     s.free(x0);
     x = vae_resnet(s, "decoder.mid_block.resnets.0.", x, H, W, ctop, G, eps);
     x = vae_mid_attn(s, "decoder.mid_block.attentions.0.", x, G, eps);
@@ -228,7 +292,7 @@ void vae_decode_walk(Walk& s, const fie_vae_config* cfg, const void* z, void* ou
         const int cout = cfg->block_out_channels[nb - 1 - i];
         for (int j = 0; j <= L; ++j) x = vae_resnet(s, "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", x, H, W, cout, G, eps);
         if (i != nb - 1) {
-            T u = s.conv("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", x, 1, H, W, cout, 1);
+            T u = s.upsample_conv("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv", x, 1, H, W, cout, G);
             s.free(x);
             x = u;
             H *= 2; W *= 2;
@@ -246,12 +310,12 @@ void vae_encode_walk(Walk& s, const fie_vae_config* cfg, const void* x_in, void*
     const float eps = cfg->norm_eps;
     int H = cfg->latent_h << (nb - 1), W = cfg->latent_w << (nb - 1);
     T xin = Walk::ext(x_in, (int64_t)H * W, 8);
-    T x = s.conv("encoder.conv_in", xin, 1, H, W, cfg->block_out_channels[0]);
+    T x = s.conv("encoder.conv_in", xin, 1, H, W, cfg->block_out_channels[0], 0, 1, 0, FIE_ACT_NONE, nullptr, nullptr, 0, nullptr, G);
     for (int i = 0; i < nb; ++i) {
         const int cout = cfg->block_out_channels[i];
         for (int j = 0; j < L; ++j) x = vae_resnet(s, "encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", x, H, W, cout, G, eps);
         if (i != nb - 1) {                                   // F.pad(0, 1, 0, 1) + stride-2 conv without padding
-            T d = s.conv("encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", x, 1, H, W, cout, 0, 2, 1);
+            T d = s.conv("encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", x, 1, H, W, cout, 0, 2, 1, FIE_ACT_NONE, nullptr, nullptr, 0, nullptr, G);
             s.free(x);
             x = d;
             H /= 2; W /= 2;
@@ -345,17 +409,19 @@ T unet_resnet(Walk& s, Cond& c, const std::string& p, T x, int H, int W, int cou
     T y = s.gnorm(p + "norm1", x, B, G, cfg->norm_eps, 1, skip);
     const void* rb = s.plan() ? nullptr : static_cast<const void*>(s.p(c.temb, c.tcol));
     c.tcol += cout;
-    T y1 = s.conv(p + "conv1", y, B, H, W, cout, 0, 1, 0, FIE_ACT_NONE, nullptr, rb, c.temb.c);
+    T y1 = s.conv(p + "conv1", y, B, H, W, cout, 0, 1, 0, FIE_ACT_NONE, nullptr, rb, c.temb.c, nullptr, G);
     s.free(y);
     T y2 = s.gnorm(p + "norm2", y1, B, G, cfg->norm_eps, 1);
     s.free(y1);
     T out;
-    if (cin != cout) {
+    if (cin != cout && x.c % 64 == 0 && cout % 64 == 0 && (!skip || skip->c % 64 == 0) && s.fused(p + "conv2_plus.weight")) {
+        out = s.conv_plus(p + "conv2_plus", y2, B, H, W, cout, x, skip, G);
+    } else if (cin != cout) {
         T sc = s.linear(p + "conv_shortcut", x, cout, FIE_ACT_NONE, nullptr, 1.f, skip);
-        out = s.conv(p + "conv2", y2, B, H, W, cout, 0, 1, 0, FIE_ACT_NONE, &sc);
+        out = s.conv(p + "conv2", y2, B, H, W, cout, 0, 1, 0, FIE_ACT_NONE, &sc, nullptr, 0, nullptr, G);
         s.free(sc);
     } else {
-        out = s.conv(p + "conv2", y2, B, H, W, cout, 0, 1, 0, FIE_ACT_NONE, &x);
+        out = s.conv(p + "conv2", y2, B, H, W, cout, 0, 1, 0, FIE_ACT_NONE, &x, nullptr, 0, nullptr, G);
     }
     s.free(y2);
     s.free(x);
@@ -400,7 +466,7 @@ T unet_transformer(Walk& s, Cond& c, const std::string& p, T x, int depth, int t
     T h = s.linear(p + "proj_in", h0, x.c);
     s.free(h0);
     for (int k = 0; k < depth; ++k) h = unet_tblock(s, c, p + "transformer_blocks." + std::to_string(k) + ".", h, tokens);
-    T o = s.linear(p + "proj_out", h, x.c, FIE_ACT_NONE, &x);
+    T o = s.linear(p + "proj_out", h, x.c, FIE_ACT_NONE, &x, 1.f, nullptr, nullptr, 0, 0, nullptr, true, tokens, c.cfg->norm_num_groups);   // the next resnet's norm1 reads this
     s.free(h);
     s.free(x);
     return o;
@@ -459,7 +525,8 @@ void unet_encode(Walk& s, Cond& c, T x, std::vector<T>& skips, T& mid) {
             skips.push_back(x);
         }
         if (i != cfg->num_blocks - 1) {
-            x = s.conv("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", x, cfg->batch, H, W, cout, 0, 2, 0);
+            x = s.conv("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", x, cfg->batch, H, W, cout, 0, 2, 0, FIE_ACT_NONE, nullptr, nullptr, 0, nullptr,
+                       cfg->norm_num_groups);
             H /= 2; W /= 2;
             skips.push_back(x);
         }
@@ -558,7 +625,7 @@ void unet_walk(Walk& s, const fie_unet_config* cfg, const void* x, const float* 
             if (cfg->up_attn[i][j]) xr = unet_transformer(s, c, "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", xr, cfg->up_attn[i][j], H * W);
         }
         if (i != nb - 1) {
-            T u = s.conv("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", xr, B, H, W, cout, 1);
+            T u = s.upsample_conv("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", xr, B, H, W, cout, 0);
             s.free(xr);
             xr = u;
             H *= 2; W *= 2;
@@ -573,6 +640,20 @@ void unet_walk(Walk& s, const fie_unet_config* cfg, const void* x, const float* 
 }
 
 constexpr int64_t kPlanCap = (int64_t)1 << 46;
+
+// The high-water mark of a walk, sized for a host that registered the optional fused matrices and for one that did not (the larger of the two;
+// a host that registered only some of them gets a loud "workspace too small" in the unlikely case first-fit packs that mix worse than both).
+template <class F>
+int64_t plan_both(const char* who, F&& walk) {
+    int64_t high = 0;
+    for (int fused = 0; fused < 2; ++fused) {
+        Walk s(nullptr, who, "", nullptr, kPlanCap);
+        s.plan_fused = fused != 0;
+        walk(s);
+        if (s.arena.high > high) high = s.arena.high;
+    }
+    return high;
+}
 
 }  // namespace
 
@@ -595,9 +676,7 @@ int64_t fie_vae_decode_workspace_bytes(const fie_vae_config* cfg, int h, int w) 
     if (!vae_cfg_ok(cfg) || h <= 0 || w <= 0) return -1;
     fie_vae_config c = *cfg;
     c.latent_h = h; c.latent_w = w;
-    Walk s(nullptr, "fie_vae_decode_workspace_bytes", "", nullptr, kPlanCap);
-    vae_decode_walk(s, &c, nullptr, nullptr);
-    return s.arena.high;
+    return plan_both("fie_vae_decode_workspace_bytes", [&](Walk& s) { vae_decode_walk(s, &c, nullptr, nullptr); });
 }
 
 int fie_vae_decode_f16(fie_ctx* ctx, const fie_vae_config* cfg, const void* z, void* out, void* workspace, int64_t workspace_bytes) {
@@ -611,9 +690,7 @@ int fie_vae_decode_f16(fie_ctx* ctx, const fie_vae_config* cfg, const void* z, v
 
 int64_t fie_vae_encode_workspace_bytes(const fie_vae_config* cfg) {
     if (!vae_cfg_ok(cfg)) return -1;
-    Walk s(nullptr, "fie_vae_encode_workspace_bytes", "", nullptr, kPlanCap);
-    vae_encode_walk(s, cfg, nullptr, nullptr);
-    return s.arena.high;
+    return plan_both("fie_vae_encode_workspace_bytes", [&](Walk& s) { vae_encode_walk(s, cfg, nullptr, nullptr); });
 }
 
 int fie_vae_encode_f16(fie_ctx* ctx, const fie_vae_config* cfg, const void* x, void* moments, void* workspace, int64_t workspace_bytes) {
@@ -649,9 +726,7 @@ int fie_unet_num_residuals(const fie_unet_config* cfg) { return unet_cfg_ok(cfg)
 
 int64_t fie_unet_workspace_bytes(const fie_unet_config* cfg) {
     if (!unet_cfg_ok(cfg)) return -1;
-    Walk s(nullptr, "fie_unet_workspace_bytes", "", nullptr, kPlanCap);
-    unet_walk(s, cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    return s.arena.high;
+    return plan_both("fie_unet_workspace_bytes", [&](Walk& s) { unet_walk(s, cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); });
 }
 
 int fie_unet_forward_f16(fie_ctx* ctx, const fie_unet_config* cfg, const char* prefix, const void* x, const float* t, const void* text, const void* pooled,
@@ -669,9 +744,8 @@ int fie_unet_forward_f16(fie_ctx* ctx, const fie_unet_config* cfg, const char* p
 
 int64_t fie_controlnet_workspace_bytes(const fie_unet_config* cfg) {
     if (!unet_cfg_ok(cfg) || cfg->num_cond_channels < 1 || cfg->num_cond_channels > 8) return -1;
-    Walk s(nullptr, "fie_controlnet_workspace_bytes", "", nullptr, kPlanCap);
-    controlnet_walk(s, cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, nullptr);
-    return s.arena.high;
+    return plan_both("fie_controlnet_workspace_bytes",
+                     [&](Walk& s) { controlnet_walk(s, cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, nullptr); });
 }
 
 int fie_controlnet_forward_f16(fie_ctx* ctx, const fie_unet_config* cfg, const char* prefix, const void* x, const float* t, const void* text, const void* pooled,

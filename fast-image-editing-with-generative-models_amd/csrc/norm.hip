@@ -36,7 +36,7 @@ struct GnArgsT {
 using GnArgs = GnArgsT<half_t>;
 
 __device__ __forceinline__ int gn_pack4_f8(const float* o, float inv) {
-    auto q = [&](float x) { return fminf(fmaxf(x * inv, -448.f), 448.f); };
+    auto q = [&](float x) { return fie_sat448(x * inv); };
     int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q(o[0]), q(o[1]), 0, false);
     return __builtin_amdgcn_cvt_pk_fp8_f32(q(o[2]), q(o[3]), pk, true);
 }
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* X, int64_t ldx, T* Y, 
             for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * (HOIST ? g[HOIST ? i : 0][j] : gl[j]) + (HOIST ? bb[HOIST ? i : 0][j] : bl[j]);
             if constexpr (O8) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = fminf(fmaxf(o[j] * inv8, -448.f), 448.f);
+                for (int j = 0; j < 8; ++j) o[j] = fie_sat448(o[j] * inv8);
                 int lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
                 lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], lo, true);
                 int hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], 0, false);

@@ -320,6 +320,27 @@ __global__ __launch_bounds__(256) void add_kernel(const half_t* a, const half_t*
     }
 }
 
+// max |x| over a [rows, C] f16 tensor, folded into *out with an atomic max on the bit pattern (non-negative floats order like unsigned integers):
+// the one-pass activation-scale calibration of the fp8 configuration (fie_amd/pipe.py: calibrate_fp8).  NaN / Inf are skipped.
+__global__ __launch_bounds__(256) void amax_kernel(const half_t* x, int64_t ldx, int64_t rows, int cols8, unsigned* out) {
+    const int64_t n = rows * cols8;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols8;
+        const int c = (int)(i - r * cols8) * 8;
+        float v[8];
+        fie_load8(x + r * ldx + c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float av = fabsf(v[j]);
+            if (av <= 65504.f) m = fmaxf(m, av);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 // dst[r, 0..cols) = src[r, 0..cols) for `rows` rows (cols % 8 == 0; row strides in elements)
 __global__ __launch_bounds__(256) void copy_rows_kernel(const half_t* src, int64_t lds_, half_t* dst, int64_t ldd, int rows, int cols8) {
     const int64_t n = (int64_t)rows * cols8;
@@ -335,6 +356,14 @@ int fie_add_f16(fie_ctx* ctx, const void* a, const void* b, void* out, int64_t n
     FIE_REQUIRE(ctx && a && b && out && n > 0 && n % 8 == 0, "fie_add_f16: bad argument");
     const int64_t n8 = n / 8, blocks = (n8 + 255) / 256;
     fie_launch(ctx, add_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (const half_t*)a, (const half_t*)b, (half_t*)out, n8);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+int fie_amax_f16(fie_ctx* ctx, const void* X, int64_t ldx, int64_t rows, int C, float* amax) {
+    FIE_REQUIRE(ctx && X && amax && rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0, "fie_amax_f16: bad argument");
+    const int64_t n = rows * (C / 8), blocks = (n + 255) / 256;
+    fie_launch(ctx, amax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (const half_t*)X, ldx, rows, C / 8, reinterpret_cast<unsigned*>(amax));
     FIE_LAUNCH_CHECK();
     return FIE_OK;
 }

@@ -61,6 +61,7 @@ SIGNATURES = {
     "fie_layernorm_f16_o8": [_P, _P, _L, _P, _L, _L, _I, _P, _P, _F, _F],
     "fie_attention_f16_o8": [_P, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I, _F],
     "fie_quantize_f8": [_P, _P, _L, _P, _L, _L, _I, _F],
+    "fie_amax_f16": [_P, _P, _L, _L, _I, _P],
     "fie_groupnorm_nhwc_f16_o8": [_P, _P, _I, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _F],
     "fie_groupnorm_stats_nhwc_f16_o8": [_P, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _P, _I, _F],
     "fie_conv3x3_x8_nhwc_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _F, _P, _L, _I, _P, _P, _L, _P, _L, _F, _I],
@@ -273,6 +274,7 @@ class Context:
         # fp8 ACTIVATIONS for the transformer-block projections of an fp8-weight model (csrc/gemm_x8.hip): the producers (LayerNorm, attention,
         # the GEGLU epilogue) write e4m3 and the GEMMs run the block-scaled MFMA.  FIE_A8=0 keeps fp16 activations (round-2 behaviour: A/B)
         self.a8 = os.environ.get("FIE_A8", "1") != "0"
+        self.calib = False             # True during HipImg2ImgPipeline.calibrate_fp8: fp8-activation layers run f16 activations and record max |x|
         # Tile / split-K choices from a file (include/fie.h: fie_gemm_autotune_load): FIE_TUNE_TABLE=<report of an earlier process>.  With
         # FIE_TUNE_FROZEN=1 the pipelines never time anything new (shapes outside the table use the built-in rule): one choice per shape on
         # every box, which is what the test session pins (tests/conftest.py); direct ctx.autotune(1) calls still tune live.
@@ -720,6 +722,13 @@ class Context:
         out = self._alloc((rows, c), torch.uint8)
         _chk(lib().fie_quantize_f8(self.h, _p(x), x.stride(0), _p(out), out.stride(0), rows, c, float(inv_scale)))
         return out
+
+    def amax_into(self, x, slot):
+        """Folds max |x| of a [..., C] f16 tensor (last dim contiguous, uniform row stride) into the device float `slot` (fp8 calibration)."""
+        self.sync_stream()
+        x2 = x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x
+        assert x2.dim() == 2 and x2.stride(1) == 1 and x2.dtype == torch.float16 and slot.dtype == torch.float32
+        _chk(lib().fie_amax_f16(self.h, _p(x2), x2.stride(0), x2.shape[0], x2.shape[1], _p(slot)))
 
     def layernorm(self, x, gamma, beta, eps=1e-5, out=None, out_f8=False, out_inv_scale=1.0):
         self.sync_stream()

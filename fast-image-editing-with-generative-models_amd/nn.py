@@ -74,12 +74,13 @@ class Conv3:
             b = bb
         self.b = b
 
-    def __call__(self, ctx, x, stride=1, pad_mode=0, upsample=False, rowbias=None, residual=None, act=hip.ACT_NONE, gn_groups=None):
-        """gn_groups: the output feeds a GroupNorm with that many groups -- have the epilogue leave its partial sums (hip.py: _gn_stats_arm)."""
+    def __call__(self, ctx, x, stride=1, pad_mode=0, upsample=False, rowbias=None, residual=None, act=hip.ACT_NONE, gn_groups=None, a_scale=1.0):
+        """gn_groups: the output feeds a GroupNorm with that many groups -- have the epilogue leave its partial sums (hip.py: _gn_stats_arm).
+        a_scale: the dequantisation scale of e4m3 input activations (1 / the producer's out_inv_scale)."""
         if upsample and self.wp4 is not None and ctx.up2x_parity and residual is None and stride == 1 and pad_mode == 0:
             return ctx.conv_up2x(x, self.wp4, self.n, bias=self.b, rowbias=rowbias, act=act, gn_groups=gn_groups)
         return ctx.conv3x3(x, self.wp, self.n, stride=stride, pad_mode=pad_mode, upsample=upsample, bias=self.b,
-                           rowbias=rowbias, residual=residual, act=act, ldc=max(self.ldc, self.n), gn_groups=gn_groups)
+                           rowbias=rowbias, residual=residual, act=act, ldc=max(self.ldc, self.n), gn_groups=gn_groups, a_scale=a_scale)
 
 
 class Norm:
@@ -94,6 +95,9 @@ class Resnet:
         self.c1, self.c2 = Conv3(ctx, sd, p + "conv1"), Conv3(ctx, sd, p + "conv2")
         self.sc = Linear(ctx, sd, p + "conv_shortcut") if p + "conv_shortcut.weight" in sd else None
         self.temb_slot = temb_slot              # (col0, col1) into the fused time-embedding projection
+        # fp8 activations: the dequantisation scales of the two GroupNorm outputs the convs read as e4m3 (value = byte * s8[i]); 1 until
+        # HipImg2ImgPipeline.calibrate_fp8 measured them (powers of two).  amax: the device floats a calibration pass folds max |x| into
+        self.s8, self.amax = [1.0, 1.0], None
         # conv2 + the 1x1 shortcut as ONE GEMM (fie_conv3x3_plus_nhwc_f16): conv2's packed matrix with the shortcut's columns appended
         self.wp_plus = None
         if self.sc is not None and torch.is_tensor(self.c2.wp) and torch.is_tensor(self.sc.wp) and self.c2.wp.dtype == torch.float16:
@@ -105,10 +109,16 @@ class Resnet:
 
     def __call__(self, ctx, x, temb_all=None, skip=None):
         b, h, w, _ = x.shape
-        y = ctx.groupnorm(x, self.n1.g, self.n1.b, self.groups, self.eps, True, x2=skip, out_f8=self.c1.a8)      # fp8 model: e4m3 for an fp8-activation conv
+        calib = ctx.calib and self.amax is not None             # calibration pass: f16 activations (the fp8-weight kernels take them), max |x| recorded
+        q1, q2 = self.c1.a8 and not calib, self.c2.a8 and self.wp_plus is None and not calib
+        y = ctx.groupnorm(x, self.n1.g, self.n1.b, self.groups, self.eps, True, x2=skip, out_f8=q1, out_inv_scale=1.0 / self.s8[0])   # fp8 model: e4m3 for an fp8-activation conv
+        if calib and self.c1.a8:
+            ctx.amax_into(y, self.amax[0:1])
         rb = temb_all[:, self.temb_slot[0]:self.temb_slot[1]] if self.temb_slot is not None else None
-        y = self.c1(ctx, y, rowbias=rb, gn_groups=self.groups)          # norm2's first pass rides on conv1's epilogue where the group width allows
-        y = ctx.groupnorm(y, self.n2.g, self.n2.b, self.groups, self.eps, True, out_f8=self.c2.a8 and self.wp_plus is None)
+        y = self.c1(ctx, y, rowbias=rb, gn_groups=self.groups, a_scale=self.s8[0] if q1 else 1.0)     # norm2's first pass rides on conv1's epilogue where the group width allows
+        y = ctx.groupnorm(y, self.n2.g, self.n2.b, self.groups, self.eps, True, out_f8=q2, out_inv_scale=1.0 / self.s8[1])
+        if calib and self.c2.a8 and self.wp_plus is None:
+            ctx.amax_into(y, self.amax[1:2])
         if self.wp_plus is not None and ctx.conv_plus_shortcut and x.shape[-1] % 64 == 0 and (skip is None or skip.shape[-1] % 64 == 0):
             return ctx.conv3x3_plus(y, self.wp_plus, self.c2.n, x.view(b * h * w, -1), None if skip is None else skip.view(b * h * w, -1),
                                     bias=self.b_plus, gn_groups=self.groups)
@@ -117,7 +127,7 @@ class Resnet:
             res = res.view(b, h, w, -1)
         else:
             res = x
-        return self.c2(ctx, y, residual=res, gn_groups=self.groups)      # ... and the next block's norm on conv2's
+        return self.c2(ctx, y, residual=res, gn_groups=self.groups, a_scale=self.s8[1] if q2 else 1.0)      # ... and the next block's norm on conv2's
 
 
 class TBlock:
@@ -135,43 +145,55 @@ class TBlock:
         self.kv_cache = None
         # BASELINE config 5: every projection whose input is produced by LayerNorm / attention / the GEGLU epilogue reads e4m3 activations
         self.a8 = all(l.a8 for l in (self.qkv, self.o1, self.q2, self.o2, self.ff1, self.ff2)) and head_dim == 64
+        # dequantisation scales of the six e4m3 tensors of the block (LN1, attention 1, LN2, attention 2, LN3, GEGLU output): value = byte * s8[i].
+        # 1 until HipImg2ImgPipeline.calibrate_fp8 measured them (powers of two: exact both ways); amax: the calibration pass's device floats
+        self.s8, self.amax = [1.0] * 6, None
 
     def _call_a8(self, ctx, h, text, batch, tokens, text_len):
-        """The block with fp8 activations: LayerNorm, attention and the GEGLU epilogue WRITE e4m3 (unit scale, saturating RNE -- the values the
-        fp8-weight kernels of round 2 converted per fragment), the six projections run the block-scaled fp8 MFMA; h, q, k, v stay fp16."""
-        c = self.c
-        y = ctx.layernorm(h, self.ln[0].g, self.ln[0].b, out_f8=True)
-        qkv = self.qkv(ctx, y)
-        a = ctx.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], self.heads, self.hd, tokens, tokens, batch, out_f8=True)
-        h = self.o1(ctx, a, residual=h)
-        y = ctx.layernorm(h, self.ln[1].g, self.ln[1].b, out_f8=True)
-        q = self.q2(ctx, y)
+        """The block with fp8 activations: LayerNorm, attention and the GEGLU epilogue WRITE e4m3 (value / s8[i], saturating RNE; s8 = 1 gives the
+        values the fp8-weight kernels of round 2 converted per fragment), the six projections run the block-scaled fp8 MFMA with a_scale = s8[i]
+        folded into the per-channel weight scale; h, q, k, v stay fp16."""
+        c, s = self.c, self.s8
+        y = ctx.layernorm(h, self.ln[0].g, self.ln[0].b, out_f8=True, out_inv_scale=1.0 / s[0])
+        qkv = self.qkv(ctx, y, a_scale=s[0])
+        a = ctx.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], self.heads, self.hd, tokens, tokens, batch, out_f8=True, out_inv_scale=1.0 / s[1])
+        h = self.o1(ctx, a, residual=h, a_scale=s[1])
+        y = ctx.layernorm(h, self.ln[1].g, self.ln[1].b, out_f8=True, out_inv_scale=1.0 / s[2])
+        q = self.q2(ctx, y, a_scale=s[2])
         if self.kv_cache is None:
             self.kv_cache = self.kv2(ctx, text)
         kv = self.kv_cache
-        a = ctx.attention(q, kv[:, :c], kv[:, c:], self.heads, self.hd, tokens, text_len, batch, out_f8=True)
-        h = self.o2(ctx, a, residual=h)
-        y = ctx.layernorm(h, self.ln[2].g, self.ln[2].b, out_f8=True)
-        f = self.ff1(ctx, y, out_f8=True)
-        return self.ff2(ctx, f, residual=h)
+        a = ctx.attention(q, kv[:, :c], kv[:, c:], self.heads, self.hd, tokens, text_len, batch, out_f8=True, out_inv_scale=1.0 / s[3])
+        h = self.o2(ctx, a, residual=h, a_scale=s[3])
+        y = ctx.layernorm(h, self.ln[2].g, self.ln[2].b, out_f8=True, out_inv_scale=1.0 / s[4])
+        f = self.ff1(ctx, y, a_scale=s[4], out_f8=True, out_inv_scale=1.0 / s[5])
+        return self.ff2(ctx, f, residual=h, a_scale=s[5])
 
     def __call__(self, ctx, h, text, batch, tokens, text_len):
-        if self.a8:
+        am = self.amax if ctx.calib and self.a8 else None      # calibration pass of an fp8 model: the f16-activation path below, max |x| of the six tensors recorded
+        if self.a8 and am is None:
             return self._call_a8(ctx, h, text, batch, tokens, text_len)
+        rec = (lambda t, i: ctx.amax_into(t, am[i:i + 1])) if am is not None else (lambda t, i: None)
         c = self.c
         y = ctx.layernorm(h, self.ln[0].g, self.ln[0].b)
+        rec(y, 0)
         qkv = self.qkv(ctx, y)
         a = ctx.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], self.heads, self.hd, tokens, tokens, batch)
+        rec(a, 1)
         h = self.o1(ctx, a, residual=h)
         y = ctx.layernorm(h, self.ln[1].g, self.ln[1].b)
+        rec(y, 2)
         q = self.q2(ctx, y)
         if self.kv_cache is None:                 # text is invariant over the denoising steps of one image
             self.kv_cache = self.kv2(ctx, text)
         kv = self.kv_cache
         a = ctx.attention(q, kv[:, :c], kv[:, c:], self.heads, self.hd, tokens, text_len, batch)
+        rec(a, 3)
         h = self.o2(ctx, a, residual=h)
         y = ctx.layernorm(h, self.ln[2].g, self.ln[2].b)
+        rec(y, 4)
         f = self.ff1(ctx, y)
+        rec(f, 5)
         return self.ff2(ctx, f, residual=h)
 
 

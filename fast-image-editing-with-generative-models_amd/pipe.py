@@ -286,6 +286,56 @@ class HipImg2ImgPipeline:
             finally:
                 self.ctx.autotune(2 if self.autotune else 0)
 
+    # ------------------------------------------------------------------------------------------------ fp8 activation scales (config 5)
+    def _fp8_layers(self):
+        """(name, layer) of every layer that reads e4m3 activations: the transformer blocks (six tensors each) and the fp8-activation resnets (two)."""
+        out = []
+        for mname, net in (("unet", self.unet), ("controlnet", self.controlnet)):
+            for i, t in enumerate(net.transformers()):
+                out += [(f"{mname}.transformer{i}.block{k}", b) for k, b in enumerate(t.blocks) if b.a8]
+            out += [(mname + "." + p.rstrip("."), r) for p, r in net.temb_names if r.c1.a8 or (r.c2.a8 and r.wp_plus is None)]
+        return out
+
+    def calibrate_fp8(self, prompt, image, control_image, margin=2.0, **edit_kw):
+        """One-pass activation-scale calibration of the fp8 configuration (weight_dtype="f8e4m3"; include/fie.h: fie_amax_f16).  Runs ONE eager edit
+        with the fp8-activation layers on f16 activations, folding max |x| of every tensor they would have quantised into a device float; then
+        sets, per tensor, the power-of-two scale s = 2^ceil(log2(amax * margin / 448)) -- the producer writes value / s as e4m3, the consumer folds
+        s into its per-channel weight scale.  A tensor beyond +-448 is no longer clipped, a small one uses the upper binades of e4m3 instead of its
+        subnormals.  Captured graphs hold the old scales and are dropped.  Returns {layer name: [scales]} (load_fp8_scales takes it back)."""
+        import math
+        if self.weight_dtype != "f8e4m3":
+            raise ValueError("calibrate_fp8: the pipeline was not built with weight_dtype='f8e4m3'")
+        layers = self._fp8_layers()
+        for _, l in layers:
+            l.amax = torch.zeros(len(l.s8), device=self.ctx.device, dtype=torch.float32)
+        graph, self.use_graph, self.ctx.calib = self.use_graph, False, True
+        try:
+            self(prompt=prompt, image=image, control_image=control_image, **edit_kw)
+        finally:
+            self.use_graph, self.ctx.calib = graph, False
+        torch.cuda.synchronize(self.ctx.device)
+        scales = {}
+        for name, l in layers:
+            am = l.amax.cpu().tolist()
+            l.amax = None
+            l.s8 = [2.0 ** math.ceil(math.log2(a * margin / 448.0)) if a > 0 else 1.0 for a in am]
+            scales[name] = list(l.s8)
+        self._graphs.clear()
+        self._n_forked = 0
+        return scales
+
+    def load_fp8_scales(self, scales):
+        """Scales from an earlier calibrate_fp8 of the same model (a JSON-able dict); unknown / missing layer names raise."""
+        layers = dict(self._fp8_layers())
+        if set(scales) != set(layers):
+            raise ValueError(f"load_fp8_scales: layer names differ ({len(set(scales) ^ set(layers))} unmatched)")
+        for name, sc in scales.items():
+            if len(sc) != len(layers[name].s8) or any(not (v > 0) for v in sc):
+                raise ValueError(f"load_fp8_scales: bad scales for {name}")
+            layers[name].s8 = [float(v) for v in sc]
+        self._graphs.clear()
+        self._n_forked = 0
+
     def _tune_mode(self):
         """fie_gemm_autotune mode of a pass that may meet new shapes: 1 (time them), or 2 (remembered choices only) when the context's choices
         are frozen to a loaded table (FIE_TUNE_TABLE + FIE_TUNE_FROZEN=1: the test session), 0 with FIE_AUTOTUNE=0."""

@@ -297,9 +297,13 @@ int fie_conv3x3_w8_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, in
  * attention.py BasicTransformerBlock: to_q/k/v, to_out, GEGLU proj, FF out) read e4m3 activations written by their PRODUCER -- LayerNorm
  * (fie_layernorm_f16_o8), attention (fie_attention_f16_o8), the FF1 GEGLU epilogue (fie_gemm_x8_f16 with out_f8) -- and multiply them with
  * e4m3 weights on the block-scaled MFMA v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: twice the fp16 MFMA rate and half the
- * operand bytes.  Quantisation: value * inv_scale, round to nearest even, saturated to +-448; the consumer multiplies the fp32 accumulator by
- * a_scale (= 1 / inv_scale of its input, one per tensor) * w_scale[n].  The residual stream, q/k/v and every GEMM output that is not a
- * GEMM input stay fp16.
+ * operand bytes.  Quantisation: value * inv_scale, round to nearest even, finite values saturated to +-448; a NaN is written as the e4m3 NaN
+ * and +-Inf as NaN too (a blow-up upstream stays visible: the consuming MFMA spreads it); the consumer multiplies the fp32 accumulator by
+ * a_scale (= 1 / inv_scale of its input, one per tensor) * w_scale[n].  inv_scale is the caller's: 1 clips activations beyond +-448 without
+ * a signal, so a host calibrates it -- fie_amax_f16 folds max |x| of a tensor into a device float (atomic max; the caller zeroes it), run over
+ * one representative edit with f16 activations, and inv_scale = 2^-k with k = ceil(log2(amax * margin / 448)) per quantised tensor (a power of
+ * two: scaling is exact in both directions; fie_amd/pipe.py::calibrate_fp8 does this with margin 2).  The residual stream, q/k/v and every
+ * GEMM output that is not a GEMM input stay fp16.
  *   fie_gemm_x8_f16: A8 [M, K] e4m3 bytes (row stride lda BYTES, K % 16 == 0, lda % 16 == 0); W8packed / w_scale from fie_pack_rows_f8 with
  *     ldw % 128 == 0; epilogue as fie_gemm_f16; out_f8 != 0: C is e4m3 bytes (value * out_inv_scale; ldc in BYTES; GEGLU: N / 2 bytes per row;
  *     no residual), else f16 (ldc in elements).
@@ -312,6 +316,7 @@ int fie_layernorm_f16_o8(fie_ctx* ctx, const void* X, int64_t ldx, void* Y8, int
 int fie_attention_f16_o8(fie_ctx* ctx, const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O8, int64_t ldo8,
                          int B, int H, int Tq, int Tk, int D, float scale, int causal, float inv_scale);
 int fie_quantize_f8(fie_ctx* ctx, const void* X, int64_t ldx, void* Y8, int64_t ldy, int64_t rows, int C, float inv_scale);
+int fie_amax_f16(fie_ctx* ctx, const void* X, int64_t ldx, int64_t rows, int C, float* amax);
 /* The resnet convs of an fp8 model (upstream resnet.py: GroupNorm -> SiLU -> conv): GroupNorm writes e4m3 (the _o8 twins of fie_groupnorm_nhwc_f16 /
  * fie_groupnorm_stats_nhwc_f16; Y8 = [B, rows, C] bytes) and fie_conv3x3_x8_nhwc_f16 runs the conv view of the same block-scaled MFMA kernel: X8 NHWC
  * e4m3 with Cin % 128 == 0 (a K-step is 128 channels of one tap), W8packed from fie_pack_conv3x3_f8 with cin_pad == Cin; output f16.  Conv + 1x1 side

@@ -213,6 +213,55 @@ def test_fp8_activations_beyond_e4m3_range_saturate(fie8):
     assert torch.isfinite(o_w8.float()).all() and rel_err(o_w8, ref) < 2e-3 and rel_err(o_x8, ref) < 2e-3
 
 
+def test_calibrated_activation_scale_beyond_448_is_not_clipped(fie8):
+    """VERDICT r3 item 7: activations beyond +-448 at unit scale are CLIPPED by the e4m3 producers (the result is far from the true product);
+    with the calibrated power-of-two scale (fie_amax_f16 -> s = 2^ceil(log2(amax / 448)); producer writes value / s, consumer multiplies by s)
+    the same layer matches the unquantised fp32 product to e4m3 rounding.  LayerNorm producer (|y| up to ~1 600) -> fp8-activation GEMM."""
+    import math
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(512, 1280, generator=g).half()
+    gam, bet = (300 * (1 + 0.2 * torch.randn(1280, generator=g))).half(), (0.1 * torch.randn(1280, generator=g)).half()
+    w = rnd(640, 1280, seed=22, scale=1280 ** -0.5)
+    wp = fie8.pack_linear(w.to(DEV))
+    y16 = fie8.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV))
+    slot = torch.zeros(1, device=DEV, dtype=torch.float32)
+    fie8.amax_into(y16, slot)
+    fie8.amax_into(y16[:7], slot)                     # folding a smaller maximum leaves it
+    amax = slot.item()
+    assert amax == y16.float().abs().max().item() and amax > 1000
+    true = y16.float().cpu() @ w.float().T
+    clipped = fie8.gemm(fie8.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), out_f8=True), wp, 640)
+    s = 2.0 ** math.ceil(math.log2(amax / 448.0))
+    assert s in (4.0, 8.0)
+    y8 = fie8.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), out_f8=True, out_inv_scale=1.0 / s)
+    assert y8.view(torch.float8_e4m3fn).float().abs().max().item() < 448          # nothing saturates any more
+    scaled = fie8.gemm(y8, wp, 640, a_scale=s)
+    e_clip, e_scaled = rel_err(clipped, true), rel_err(scaled, true)
+    print(f"LayerNorm (amax {amax:.0f}) -> fp8 GEMM against the unquantised product: unit scale (clipped) {e_clip:.2e}, scale {s:g} {e_scaled:.2e}")
+    assert e_clip > 0.15 and e_scaled < 3e-2
+    # ... and tight against the product of the values the kernel multiplies: e4m3(y / s) * s, e4m3 weights
+    wq = wp.q.view(torch.float8_e4m3fn).float().cpu()[:640, :1280]
+    ref = (y8.view(torch.float8_e4m3fn).float().cpu() * s) @ wq.T * wp.scale[:640].cpu()
+    assert rel_err(scaled, ref) < 2e-3
+
+
+def test_e4m3_producers_keep_nan_and_turn_inf_into_nan(fie8):
+    """ADVICE r3 (norm.hip:38): the saturating conversions clamp FINITE values to +-448; a NaN stays a NaN and +-Inf becomes one, so a numerical
+    blow-up upstream shows in the fp8 configuration's output as it would in the fp16 path's instead of turning into a plausible finite value."""
+    a = rnd(64, 256, seed=5)
+    a[3, 17], a[9, 100], a[20, 5], a[21, 6] = float("nan"), float("inf"), 60000.0, -60000.0
+    q = fie8.quantize_f8(a.to(DEV)).view(torch.float8_e4m3fn).float().cpu()
+    assert torch.isnan(q[3, 17]) and torch.isnan(q[9, 100]) and q[20, 5] == 448 and q[21, 6] == -448
+    assert torch.isnan(q).sum() == 2
+    wp = fie8.pack_linear(rnd(128, 256, seed=6, scale=1 / 16).to(DEV))
+    o = fie8.gemm(fie8.quantize_f8(a.to(DEV)), wp, 128).float().cpu()
+    assert torch.isnan(o[3]).all() and torch.isnan(o[9]).all() and torch.isfinite(o[[0, 1, 2, 20, 21]]).all()
+    x = rnd(64, 1280, seed=7)
+    x[5, 5] = float("nan")
+    y8 = fie8.layernorm(x.to(DEV), torch.ones(1280).half().to(DEV), torch.zeros(1280).half().to(DEV), out_f8=True).view(torch.float8_e4m3fn).float().cpu()
+    assert torch.isnan(y8[5]).all() and torch.isfinite(y8[4]).all()
+
+
 def test_fp8_producers_layernorm_and_attention(fie):
     """The producers of fp8 activations: LayerNorm and attention with an e4m3 output equal the fp16 op followed by the saturating
     round-to-nearest-even conversion (their fp32 values are converted once, so a code may differ where the fp16 rounding of the plain op moved

@@ -612,6 +612,42 @@ def test_halo_resident_conv(fie, code):
         fie.force_tile(0)
 
 
+def test_halo_resident_conv_with_1x1_side_inputs(fie):
+    """A resnet's conv2 + its 1x1 shortcut as one launch (include/fie.h: fie_conv3x3_plus_nhwc_f16) on the halo-resident kernel (code 72): the side
+    inputs run as centre-tap K-steps behind the nine-tap chunks.  Against torch fp32; one and several tiles per block, one and two side inputs,
+    GroupNorm sums for the consumer; repeats bit-identical; the ring kernel (code 52) agrees to the last bits' difference of a different K order."""
+    from fie_amd import hip
+    g = torch.Generator().manual_seed(72)
+    try:
+        for b, h, w, cin, cout, c2, c3, gn in [(1, 64, 64, 128, 128, 256, 0, False), (2, 64, 96, 256, 256, 128, 64, True), (1, 320, 320, 128, 128, 256, 0, True),
+                                                (2, 64, 64, 640, 640, 1280, 640, True)]:
+            x = torch.randn(b, h, w, cin, generator=g).half().to(DEV)
+            x2 = torch.randn(b * h * w, c2, generator=g).half().to(DEV)
+            x3 = torch.randn(b * h * w, c3, generator=g).half().to(DEV) if c3 else None
+            wt = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half().to(DEV)
+            w1 = (torch.randn(cout, c2 + c3, generator=g) * (c2 + c3) ** -0.5).half().to(DEV)
+            bias = torch.randn(cout, generator=g).half().to(DEV)
+            wplus = torch.cat([fie.pack_conv3x3(wt)[:, :9 * cin], fie.pack_linear(w1)[:, :c2 + c3]], 1).contiguous()
+            side = x2 if x3 is None else torch.cat([x2, x3], 1)
+            ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt.float(), bias.float(), padding=1) \
+                + (side.float() @ w1.float().T).view(b, h, w, cout).permute(0, 3, 1, 2)
+            fie.force_tile(72)
+            outs = [fie.conv3x3_plus(x, wplus, cout, x2, x3, bias=bias, gn_groups=32 if gn else None) for _ in range(5)]
+            assert "conv_halo2" in hip.last_gemm_kernel(fie), hip.last_gemm_kernel(fie)
+            assert rel_err(outs[0].permute(0, 3, 1, 2), ref) < 4e-3, (b, h, w, cin, cout, c2, c3)
+            assert all(torch.equal(o, outs[0]) for o in outs[1:]), (b, h, w, cin, cout, c2, c3)
+            fie.force_tile(52)
+            ring = fie.conv3x3_plus(x, wplus, cout, x2, x3, bias=bias)
+            assert "conv_halo" not in hip.last_gemm_kernel(fie) and rel_err(outs[0], ring.float()) < 2e-3
+            if gn:
+                fie.force_tile(0)
+                gnv = fie.groupnorm(outs[-1], torch.ones(cout).half().to(DEV), torch.zeros(cout).half().to(DEV), 32, 1e-5, True)
+                gref = F.silu(F.group_norm(outs[-1].float().permute(0, 3, 1, 2), 32, eps=1e-5))
+                assert rel_err(gnv.permute(0, 3, 1, 2), gref) < 4e-3
+    finally:
+        fie.force_tile(0)
+
+
 def test_split_k_in_launch_reduction(fie):
     """Split-K for the M = 2048 class (include/fie.h: fie_splitk_workspace; gemm_common.h: splitk_reduce): the K-steps of a tile are
     dealt to s blocks, the block that arrives last sums the fp32 slabs in slice order and runs the epilogue.  Checked: the result

@@ -72,9 +72,32 @@ def test_sdxl_eval_fp8_vs_oracle_on_dequantised_weights(sdxl_weights, fie):
     want = sdq["unet"][name].float()
     assert ((got - want).abs() <= 2e-3 * want.abs()).float().mean() > 0.999       # (a tie that rounds the other way after the fp16 round trip: one e4m3 code on a handful of elements)
     sds32 = {k: {n: v.float() for n, v in sdq[k].items()} for k in ("unet", "controlnet")}
-    e, worst = eval_vs_oracle(cfgs, sds32, p8, fie)
+    cache = {}
+    e, worst = eval_vs_oracle(cfgs, sds32, p8, fie, cache=cache)
     print(f"SDXL-base fp8 (W8A8) eval vs oracle on the dequantised weights: eps rel_err={e:.2e}, worst ControlNet residual rel_err={worst:.2e}")
     assert worst < 1.2e-1 and e < 1.2e-1
+    # the same evaluation with CALIBRATED activation scales (pipe.calibrate_fp8: one edit, per-tensor amax -> power-of-two scale): every scale a
+    # power of two, most of them < 1 on these unit-variance activations (the values move up into e4m3's normal binades); the error against the
+    # oracle must not grow (it barely moves here: e4m3's relative step is the same in every normal binade and nothing was clipping)
+    import math
+    from PIL import Image
+    from fie_amd import hip
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 255, (1024, 1024, 3), dtype=np.uint8)
+    a[200:700, 300:800] = 40
+    scales = p8.calibrate_fp8(prompt="a [blue] house", image=Image.fromarray(a), control_image=Image.fromarray(hip.canny_rgb(a)), negative_prompt="",
+                              strength=0.5, num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5,
+                              generator=torch.Generator("cpu").manual_seed(1))
+    flat = [v for sc in scales.values() for v in sc]
+    assert len(scales) > 100 and all(v > 0 and math.log2(v) == round(math.log2(v)) for v in flat) and min(flat) < 1.0
+    assert blk.s8 == scales["unet.transformer0.block0"] and any(v != 1.0 for v in blk.s8)
+    e2, worst2 = eval_vs_oracle(cfgs, sds32, p8, fie, cache=cache)
+    print(f"  ... with calibrated activation scales ({len(flat)} tensors, 2^{math.log2(min(flat)):.0f} .. 2^{math.log2(max(flat)):.0f}): eps rel_err={e2:.2e}, "
+          f"worst ControlNet residual rel_err={worst2:.2e}")
+    assert e2 < max(1.15 * e, 8e-2) and worst2 < max(1.15 * worst, 8e-2)
+    p8.load_fp8_scales(scales)                       # round trip of the dict a deployment would store next to the weights
+    with pytest.raises(ValueError, match="layer names differ"):
+        p8.load_fp8_scales({"unet.nonsense": [1.0]})
 
 
 def test_sdxl_fp8_full_size_ssim_vs_fp16(sdxl_weights, fie):
