@@ -270,6 +270,10 @@ template <bool RES, bool GN, bool RB, int VAR, bool STAMP, bool SIDE = false>
 __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
     constexpr int FM = 4, FN = 4, WN = 64;
     constexpr bool ST16 = (VAR & 2) != 0, STM = (VAR & 4) != 0, IM = (VAR & 8) != 0;
+    // DEFER: the GroupNorm sums of a tile are taken from its packed f16 outputs while the NEXT tile's first chunk runs, a few VALU instructions behind
+    // every MFMA of K-steps 0..7 (the wave's issue slot is idle 12 of every 16 cycles there), instead of ~1 400 cycles of tile-end math that both wave
+    // groups wait for; the 16-byte stores' lane swap moves to the store slot for the same reason (the sums want the unswapped layout)
+    constexpr bool DEFER = ST16 && STM && !IM;
     static_assert(!(SIDE && (RES || RB)), "1x1 side inputs belong to a resnet's conv2 + shortcut: no residual, no row bias");
     extern __shared__ __attribute__((aligned(16))) half_t smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -387,6 +391,10 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
     for (int i = 0; i < FN; ++i)
 #pragma unroll
         for (int j = 0; j < FM; ++j) outp[i][j] = (u32x2){0u, 0u};
+    // DEFER && GN: where the previous tile's sums go (slot index of its patch-row pair 0 for this wave, in float2 units) and the running pair's sums
+    unsigned gslot_prev = 0;
+    float gsum = 0.f, gsq = 0.f;
+    const int gn_sh = p.gn_cg == 16 ? 4 : p.gn_cg == 8 ? 3 : 2;      // log2(channels per group)
 
     unsigned seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;     // STAMP: [0] DMA / store issue, [1] reads, [2] wait + barrier, [3] MFMA, [4] barrier, [5] prologue, [6] flush, [7] tile-end math
     unsigned kseg[5] = {0, 0, 0, 0, 0};                           // STAMP: whole K-steps by chunk kind (first = stores, middle, last with / without prefetch)
@@ -472,6 +480,10 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
             if constexpr (ST16) {                                // store T = (fragment pair T / 4, channel fragment T % 4): 16 B per lane
                 constexpr int JJ = T / FN, I = T % FN;
                 u32x4 v = {outp[I][2 * JJ][0], outp[I][2 * JJ][1], outp[I][2 * JJ + 1][0], outp[I][2 * JJ + 1][1]};
+                if constexpr (DEFER) {                           // the lane swap of the 16-byte form, here instead of at the tile end
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v[0]), "+v"(v[2]));
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v[1]), "+v"(v[3]));
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, ro_prev + (unsigned)(2 * JJ) * c_jstep + (unsigned)(I * 32), 0, 0);
             } else {
                 const int k = 2 * T + s, j = k / FN, i = k % FN;
@@ -485,6 +497,55 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
             const int j = k / FN, i = k % FN;
             outp[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, rr_cur + (unsigned)j * r_jstep + (unsigned)(i * 32), 0, 0);
         };
+        // DEFER && GN: piece q of the sums of the previous tile's fragment pair (JJ, I) = (T / 4, T % 4), one piece behind every second MFMA.  The lane holds
+        // 4 channels (one quad) of pixel fr in patch rows 2 JJ and 2 JJ + 1: v_dot2_f32_f16 sums the f16-rounded values and their squares in fp32, four
+        // DPP adds total the 16 pixels of a row, v_permlane16/32_swap add the rows of the same group (8 / 16 channels per group); lane fr == 0 of the
+        // group's first row stores the slot (one writer per slot, fixed order: deterministic)
+        auto gn_piece = [&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            constexpr int JJ = (T & 7) / FN, I = (T & 7) % FN;
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            auto dot = [&](unsigned w) {
+                const h2 x = __builtin_bit_cast(h2, w), one = {(_Float16)1.f, (_Float16)1.f};
+                gsum = __builtin_amdgcn_fdot2(x, one, gsum, false);
+                gsq = __builtin_amdgcn_fdot2(x, x, gsq, false);
+            };
+            auto dpp = [&](auto ctl) {
+                constexpr int C = decltype(ctl)::value;
+                gsum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gsum), C, 0xF, 0xF, true));
+                gsq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gsq), C, 0xF, 0xF, true));
+            };
+            if constexpr (Q == 0) { gsum = 0.f; gsq = 0.f; dot(outp[I][2 * JJ][0]); }
+            else if constexpr (Q == 1) dot(outp[I][2 * JJ][1]);
+            else if constexpr (Q == 2) dot(outp[I][2 * JJ + 1][0]);
+            else if constexpr (Q == 3) dot(outp[I][2 * JJ + 1][1]);
+            else if constexpr (Q == 4) dpp(std::integral_constant<int, 0xB1>{});
+            else if constexpr (Q == 5) dpp(std::integral_constant<int, 0x4E>{});
+            else if constexpr (Q == 6) dpp(std::integral_constant<int, 0x141>{});
+            else if constexpr (Q == 7) dpp(std::integral_constant<int, 0x140>{});
+            else if constexpr (Q == 8 || Q == 9) {               // rows fq ^ 1 (8, 16 channels per group), then rows fq ^ 2 (16): a = b = v, swap, a + b
+                float a0 = gsum, b0 = gsum, a1 = gsq, b1 = gsq;
+                if constexpr (Q == 8) {
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
+                } else {
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
+                }
+                const bool on = gn_sh >= (Q == 8 ? 3 : 4);
+                gsum = on ? a0 + b0 : gsum;
+                gsq = on ? a1 + b1 : gsq;
+            } else if constexpr (Q == 10) {
+                const int rows_per_group = 1 << (gn_sh - 2);
+                const bool ok = fr == 0 && (fq & (rows_per_group - 1)) == 0;
+                const unsigned slot = gslot_prev + (unsigned)(JJ * (p.OW >> 4) * p.gn_G) + (unsigned)(((wn * WN + I * 16) >> gn_sh) + (fq >> (gn_sh - 2)));
+                u32x2 bits;
+                const float2 v2 = make_float2(gsum, gsq);
+                __builtin_memcpy(&bits, &v2, 8);
+                __builtin_amdgcn_raw_buffer_store_b64(bits, rs_g, ok ? slot * 8u : kOob, 0, 0);
+            }
+        };
+        constexpr bool GND = GN && DEFER && KIND == K_FIRST && T < 8;
         constexpr int NW_ = n2_w(KIND, T), NH_ = n2_h(KIND, T), NS_ = n2_st(VAR, KIND, T);
         constexpr bool RLT = RES && (KIND == K_LAST_F || KIND == K_LAST_N) && T == 8;
         // slot g (0..7) of the MFMA segment: the instruction issued behind MFMA group g (IM), or everything at once in the load segment
@@ -520,8 +581,17 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
         __builtin_amdgcn_s_setprio(1);
         auto group = [&](auto gc) {                              // MFMA group g = (k half g / 4, channel fragment g % 4): four row fragments
             constexpr int Gs = decltype(gc)::value, kh = Gs / FN, i = Gs % FN;
+            if constexpr (GND) {                                 // one piece of the deferred GroupNorm sums behind every second MFMA
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kh][i], fa[kh][0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kh][i], fa[kh][1], acc[i][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0); gn_piece(std::integral_constant<int, 2 * Gs>{}); __builtin_amdgcn_sched_barrier(0);
+                acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kh][i], fa[kh][2], acc[i][2], 0, 0, 0);
+                acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kh][i], fa[kh][3], acc[i][3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0); gn_piece(std::integral_constant<int, 2 * Gs + 1>{}); __builtin_amdgcn_sched_barrier(0);
+            } else {
 #pragma unroll
-            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kh][i], fa[kh][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kh][i], fa[kh][j], acc[i][j], 0, 0, 0);
+            }
             if constexpr (RLT) { __builtin_amdgcn_sched_barrier(0); resload1(2 * Gs); resload1(2 * Gs + 1); __builtin_amdgcn_sched_barrier(0); }
             if constexpr (IM) { __builtin_amdgcn_sched_barrier(0); slot(gc); __builtin_amdgcn_sched_barrier(0); }
             else if constexpr (STM && (Gs == 3 || Gs == 4)) { __builtin_amdgcn_sched_barrier(0); slot(gc); __builtin_amdgcn_sched_barrier(0); }
@@ -638,7 +708,7 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
                     for (int r = 0; r < 4; ++r) acc[i][j][r] += (float)r4[r];
                 }
         }
-        if constexpr (GN) {
+        if constexpr (GN && !DEFER) {
             // as gemm_common.h's epilogue (one writer per (granule, group) slot), with the slot stores as unconditional buffer stores
             const int ngrp = 16 / p.gn_cg;
             const int gn_nch = p.gn_nch ? p.gn_nch : p.gn_rows >> 5;
@@ -689,7 +759,7 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
                 __builtin_memcpy(&outp[i][j], &o, 8);
                 acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-        if constexpr (ST16) {
+        if constexpr (ST16 && !DEFER) {
             // fragments (i, 2 jj) and (i, 2 jj + 1): v_permlane16_swap exchanges the odd 16-lane rows of the first with the even rows of the second, dword by
             // dword.  Afterwards a lane of an even row (fq 0 / 2) holds 8 consecutive channels (fq / 2) * 8 .. + 7 of pixel row 2 jj, a lane of an odd row
             // the same of pixel row 2 jj + 1: one 16-byte store instead of two 8-byte ones
@@ -748,18 +818,64 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
         }
         tile_end(m0, img);
         ro_prev = ST16 ? row_off16(m0, p.ldc) : row_off(m0, p.ldc);
+        if constexpr (GN && DEFER) {
+            // slot of this wave's patch-row pair 0: granule = (row pair of the image, 16-pixel column segment) as in the tile-end form; + n0's first group
+            const int gn_nch = p.gn_nch ? p.gn_nch : p.gn_rows >> 5;
+            const int chunk = p.gn_chunk0 + ((y0 + wm * FM) >> 1) * (p.OW >> 4) + (x0 >> 4);
+            gslot_prev = (unsigned)((img * gn_nch + chunk) * p.gn_G + (n0 >> gn_sh));
+        }
         stamp(7);
         if (!have_next) break;
         tile = next; m0 = m0n; img = imgn; y0 = y0n; x0 = x0n;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();                // pairs with group 1's last barrier
-    // ---- flush: the last tile's sixteen stores
+    // ---- flush: the last tile's sixteen stores (DEFER: and its GroupNorm sums, and the lane swaps of the 16-byte form)
     if constexpr (ST16) {
+        if constexpr (GN && DEFER) {
+            static_for([&](auto tc) {
+                constexpr int TT = decltype(tc)::value;
+                constexpr int JJ = TT / FN, I = TT % FN;
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                float su = 0.f, sq = 0.f;
+                const unsigned w4[4] = {outp[I][2 * JJ][0], outp[I][2 * JJ][1], outp[I][2 * JJ + 1][0], outp[I][2 * JJ + 1][1]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const h2 x = __builtin_bit_cast(h2, w4[k]), one = {(_Float16)1.f, (_Float16)1.f};
+                    su = __builtin_amdgcn_fdot2(x, one, su, false);
+                    sq = __builtin_amdgcn_fdot2(x, x, sq, false);
+                }
+                su = row16_sum(su);
+                sq = row16_sum(sq);
+                if (gn_sh >= 3) {
+                    float a0 = su, b0 = su, a1 = sq, b1 = sq;
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
+                    su = a0 + b0; sq = a1 + b1;
+                }
+                if (gn_sh >= 4) {
+                    float a0 = su, b0 = su, a1 = sq, b1 = sq;
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
+                    su = a0 + b0; sq = a1 + b1;
+                }
+                const int rows_per_group = 1 << (gn_sh - 2);
+                const bool ok = fr == 0 && (fq & (rows_per_group - 1)) == 0;
+                const unsigned slot = gslot_prev + (unsigned)(JJ * (p.OW >> 4) * p.gn_G) + (unsigned)(((wn * WN + I * 16) >> gn_sh) + (fq >> (gn_sh - 2)));
+                u32x2 bits;
+                const float2 v2 = make_float2(su, sq);
+                __builtin_memcpy(&bits, &v2, 8);
+                __builtin_amdgcn_raw_buffer_store_b64(bits, rs_g, ok ? slot * 8u : kOob, 0, 0);
+            }, std::make_integer_sequence<int, (FM / 2) * FN>{});
+        }
 #pragma unroll
         for (int jj = 0; jj < FM / 2; ++jj)
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 u32x4 v = {outp[i][2 * jj][0], outp[i][2 * jj][1], outp[i][2 * jj + 1][0], outp[i][2 * jj + 1][1]};
+                if constexpr (DEFER) {
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v[0]), "+v"(v[2]));
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v[1]), "+v"(v[3]));
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, ro_prev + (unsigned)(2 * jj) * c_jstep + (unsigned)(i * 32), 0, 0);
             }
     } else {

@@ -189,34 +189,52 @@ __device__ __forceinline__ void epilogue_lean_scaled(const GemmArgs& p, f32x4 (&
     }
 }
 
-// The LEAN GEGLU epilogue of the big tiles (256x320: the FF1 projection): bias + value * gelu(gate) -> f16 pairs, fragment column by fragment column,
-// nothing else compiled in; same arithmetic as the full epilogue with scale 1.  The full path of these tiles inlines the generic epilogue three times.
+// The LEAN GEGLU epilogue of the big tiles (256x320: the FF1 projection): bias + value * gelu(gate) -> f16 pairs, nothing else compiled in; same
+// arithmetic as the full epilogue with scale 1.  The full path of these tiles inlines the generic epilogue three times.
+// Stores (round 4): a lane's two outputs of a fragment are 4 bytes, and 4-byte stores reach the fabric as partial sectors (round-3 PMC: WRITE_SIZE 55 MB for
+// the 21 MB output, 2.6x).  Four ROW fragments at a time, a 4x4 transpose of dwords across the four fq lane rows (two v_permlane16_swap + two
+// v_permlane32_swap) hands every lane the 16 CONTIGUOUS bytes one fragment column holds of one row: a 16-byte store per lane instead of four 4-byte ones.
 template <int FM, int FN, int WM, int WN>
 __device__ __forceinline__ void epilogue_geglu_lean(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane) {
+    static_assert(FM % 4 == 0, "row fragments are transposed in fours");
     const int fr = lane & 15, fq = lane >> 4;
-    const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
+    const int mrow = m0 + wm * WM + fr, nbase = n0 + wn * WN;
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)(p.M - 1) * p.ldc + (p.N >> 1)) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.bias), 0, p.bias ? p.N * 2 : 0, 0x00020000);
-    u32x2 bnext = __builtin_amdgcn_raw_buffer_load_b64(rs_b, (unsigned)ncol * 2u, 0, 0);       // no bias: zero-size descriptor, reads zero
+    u32x2 bnext = __builtin_amdgcn_raw_buffer_load_b64(rs_b, (unsigned)(nbase + fq * 4) * 2u, 0, 0);       // no bias: zero-size descriptor, reads zero
+    // after the transpose of row fragments 4 h .. 4 h + 3 this lane holds row fragment 4 h + fq: its row of the matrix
+    unsigned ro[FM / 4];
 #pragma unroll
-    for (int i = 0; i < FN; ++i) {
-        const int n = ncol + i * 16;
+    for (int h = 0; h < FM / 4; ++h) {
+        const int m = mrow + (4 * h + fq) * 16;
+        ro[h] = m < p.M ? (unsigned)m * (unsigned)p.ldc * 2u : 0x80000000u;
+    }
+    static_for([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
         f16x4 b;
         __builtin_memcpy(&b, &bnext, 8);
-        if (i + 1 < FN) bnext = __builtin_amdgcn_raw_buffer_load_b64(rs_b, (unsigned)(ncol + (i + 1) * 16) * 2u, 0, 0);      // one fragment column ahead: 160 accumulator registers leave no room for all five
-        const unsigned co = n < p.N ? (unsigned)n : 0xC0000000u;          // output column n / 2, two bytes each: byte offset n
-#pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            const int m = mrow + j * 16;
-            const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldc * 2u : 0x80000000u;
+        if constexpr (I + 1 < FN) bnext = __builtin_amdgcn_raw_buffer_load_b64(rs_b, (unsigned)(nbase + (I + 1) * 16 + fq * 4) * 2u, 0, 0);      // one fragment column ahead: 160 accumulator registers leave no room for all five
+        const int n = nbase + I * 16;                          // the fragment column's first value / gate column: output column n / 2, two bytes each -> byte offset n
+        const unsigned co = n < p.N ? (unsigned)n : 0xC0000000u;
+        auto pair = [&](const f32x4& a) {
             f16x2 o;
-            o[0] = (half_t)((acc[i][j][0] + (float)b[0]) * fie_gelu(acc[i][j][1] + (float)b[1]) * 1.0f);
-            o[1] = (half_t)((acc[i][j][2] + (float)b[2]) * fie_gelu(acc[i][j][3] + (float)b[3]) * 1.0f);
+            o[0] = (half_t)((a[0] + (float)b[0]) * fie_gelu(a[1] + (float)b[1]) * 1.0f);
+            o[1] = (half_t)((a[2] + (float)b[2]) * fie_gelu(a[3] + (float)b[3]) * 1.0f);
             unsigned bits;
             __builtin_memcpy(&bits, &o, 4);
-            __builtin_amdgcn_raw_buffer_store_b32(bits, rs_c, ro + co, 0, 0);
+            return bits;
+        };
+#pragma unroll
+        for (int h = 0; h < FM / 4; ++h) {
+            unsigned r0 = pair(acc[I][4 * h]), r1 = pair(acc[I][4 * h + 1]), r2 = pair(acc[I][4 * h + 2]), r3 = pair(acc[I][4 * h + 3]);
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r0), "+v"(r1));
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r2), "+v"(r3));
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r0), "+v"(r2));
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r1), "+v"(r3));
+            const u32x4 v = {r0, r1, r2, r3};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, ro[h] + co, 0, 0);
         }
-    }
+    }, std::make_integer_sequence<int, FN>{});
 }
 
 // PATCH (conv_halo.hip only): the tile is a 16x16 output patch, fragment rows p.frag_ld = OW apart (GemmArgs::frag_ld); every other kernel compiles

@@ -1,8 +1,9 @@
 """The graph-level C-ABI forwards that ARE forwards (include/fie.h: fie_clip_text_forward_f16, fie_vae_encode_f16, fie_controlnet_forward_f16,
 fie_unet_forward_f16, fie_vae_decode_f16; csrc/graphs.cpp -- SURVEY 8b): the five model calls of the pipeline call at
 /root/reference/src/pipeline.py:261-272 walked in C++ on weights registered by their diffusers names.  Checked against the Python walks
-(fie_amd/{clip,vae,nn}.py: same kernels, more fusions -- agreement to rounding), against the CPU oracle on the tiny stack, inside a hipGraph,
-and for their error behaviour (unregistered weight, short workspace)."""
+(fie_amd/{clip,vae,nn}.py: CLIP and VAE bit for bit -- same kernels, same fusions, same order; UNet / ControlNet to rounding -- the Python walk
+keeps the one-launch timestep embedding and the zero-conv adds for itself), against the CPU oracle on the tiny stack, inside a hipGraph, and
+for their error behaviour (unregistered weight, short workspace)."""
 import ctypes
 
 import pytest
@@ -32,7 +33,9 @@ def test_vae_decode_and_encode_walked_in_cpp(fie, stack_name, lat):
     assert out.shape == ref.shape
     err = _rel(out, ref)
     print(f"C++ decoder walk vs Python walk ({stack_name}, {lat}x{lat} latents): rel. max-abs error {err:.2e}")
-    assert err < 4e-3 and out[..., 3].abs().max() == 0
+    # since round 4 the C++ walk takes the Python walk's fusions (GroupNorm sums from the epilogues, conv2 + shortcut in one launch, parity
+    # up-samplers): same kernels in the same order, so the same bits
+    assert torch.equal(out, ref.half()) and out[..., 3].abs().max() == 0
     # encoder: pixels -> moments
     img = torch.zeros(1, lat * 8, lat * 8, 8, dtype=torch.float16)
     img[..., :3] = (torch.rand(1, lat * 8, lat * 8, 3, generator=g) * 2 - 1).half()
@@ -41,7 +44,7 @@ def test_vae_decode_and_encode_walked_in_cpp(fie, stack_name, lat):
     mout = cabi.vae_encode(vae, imgd)
     err = _rel(mout, mref)
     print(f"C++ encoder walk vs Python walk ({stack_name}, {lat * 8}^2 pixels): rel. max-abs error {err:.2e}")
-    assert mout.shape == mref.shape and err < 4e-3
+    assert mout.shape == mref.shape and torch.equal(mout, mref)
     if stack_name == "tiny":
         from oracle import nets
         with torch.no_grad():

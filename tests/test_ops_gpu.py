@@ -572,7 +572,8 @@ def test_halo_resident_conv(fie, code):
     g = torch.Generator().manual_seed(code)
     try:
         for b, h, w, cin, cout, opts in [(2, 32, 48, 128, 128, "bias,res"), (2, 64, 64, 256, 256, "bias,gn"), (1, 320, 320, 128, 128, "bias,res,gn"),
-                                         (2, 160, 240, 128, 256, "bias,rowbias,gn"), (1, 48, 32, 192, 320, "bias,rowbias"), (1, 16, 16, 64, 128, "")]:
+                                         (2, 160, 240, 128, 256, "bias,rowbias,gn"), (1, 48, 32, 192, 320, "bias,rowbias"), (1, 16, 16, 64, 128, ""),
+                                         (1, 160, 160, 512, 512, "bias,gn"), (2, 96, 96, 640, 640, "bias,res,gn")]:     # 16 channels per group; 20 (as 4-channel quads)
             x = torch.randn(b, h, w, cin, generator=g).half().to(DEV)
             wt = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
             bias = torch.randn(cout, generator=g).half().to(DEV) if "bias" in opts else None
