@@ -56,9 +56,11 @@ def _keep(obj, reg):
 
 
 # ---------------------------------------------------------------------------------------------------------------- VAE
-def register_vae(vae):
-    """Encoder + decoder of an fie_amd.vae.VAE under "encoder...." / "decoder...." / "quant_conv" / "post_quant_conv" (no prefix)."""
-    r = _Reg(vae.ctx, "")
+def register_vae(vae, prefix=""):
+    """Encoder + decoder of an fie_amd.vae.VAE under "<prefix>encoder...." / "decoder...." / "quant_conv" / "post_quant_conv"; vae_encode / vae_decode
+    below pass the same prefix in the config."""
+    vae._cabi_prefix = prefix
+    r = _Reg(vae.ctx, prefix)
     r.conv("encoder.conv_in", vae.e_in)
     for i, (rs, ds) in enumerate(vae.e_down):
         for j, rn in enumerate(rs):
@@ -87,9 +89,10 @@ def register_vae(vae):
     _keep(vae, r)
 
 
-def vae_config(cfg, h, w):
+def vae_config(cfg, h, w, prefix=""):
     ch = cfg["block_out_channels"]
-    return hip.VaeConfig(h, w, len(ch), (ctypes.c_int * 8)(*ch), cfg["layers_per_block"], cfg["norm_num_groups"], cfg["norm_eps"], cfg["out_channels"])
+    return hip.VaeConfig(h, w, len(ch), (ctypes.c_int * 8)(*ch), cfg["layers_per_block"], cfg["norm_num_groups"], cfg["norm_eps"], cfg["out_channels"],
+                         prefix.encode())
 
 
 def vae_encode(vae, x):
@@ -99,7 +102,7 @@ def vae_encode(vae, x):
     ctx._bind_splitk()              # the walk's GEMMs / convs split K on the ctx-bound workspace: this stream's own (include/fie.h)
     _, hh, ww, _ = x.shape
     down = 2 ** (len(vae.cfg["block_out_channels"]) - 1)
-    vc = vae_config(vae.cfg, hh // down, ww // down)
+    vc = vae_config(vae.cfg, hh // down, ww // down, getattr(vae, "_cabi_prefix", ""))
     need = hip.lib().fie_vae_encode_workspace_bytes(ctypes.byref(vc))
     assert need > 0
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)
@@ -114,12 +117,12 @@ def vae_decode(vae, z):
     ctx.sync_stream()
     ctx._bind_splitk()              # the walk's GEMMs / convs split K on the ctx-bound workspace: this stream's own (include/fie.h)
     _, h, w, _ = z.shape
-    vc = vae_config(vae.cfg, h, w)
+    vc = vae_config(vae.cfg, h, w, getattr(vae, "_cabi_prefix", ""))
     need = hip.lib().fie_vae_decode_workspace_bytes(ctypes.byref(vc), h, w)
     assert need > 0
     ws = torch.empty(need, device=z.device, dtype=torch.uint8)
     up = 2 ** (len(vae.cfg["block_out_channels"]) - 1)
-    out = torch.zeros((1, h * up, w * up, 4), device=z.device, dtype=torch.float16)
+    out = torch.empty((1, h * up, w * up, 4), device=z.device, dtype=torch.float16)      # conv_out writes all four channels (the fourth: zeros)
     hip._chk(hip.lib().fie_vae_decode_f16(ctx.h, ctypes.byref(vc), z.data_ptr(), out.data_ptr(), ws.data_ptr(), need))
     return out
 
@@ -295,18 +298,39 @@ def unet_forward(unet, prefix, x, t, text, pooled, time_ids, down_residuals=None
     return out
 
 
+def step_cache_begin(net, prefix, batch, h, w, text_len, controlnet):
+    """A new image for the model under `prefix`: bind (first time / larger shape) or reset its step cache (include/fie.h: fie_step_cache_bind) -- the
+    next forward fills it with the text K / V of every transformer block (ControlNet: and the conditioning embedding), later ones read it."""
+    uc = unet_config(net.cfg, batch, h, w, text_len)
+    need = hip.lib().fie_unet_step_cache_bytes(ctypes.byref(uc), int(controlnet))
+    assert need > 0, "fie_unet_step_cache_bytes refused the config"
+    buf = getattr(net, "_cabi_step_cache", None)
+    if buf is None or buf.numel() < need:
+        buf = net._cabi_step_cache = torch.empty(need, device=net.ctx.device, dtype=torch.uint8)
+    hip._chk(hip.lib().fie_step_cache_bind(net.ctx.h, prefix.encode(), buf.data_ptr(), buf.numel()))     # a (re)bind marks it empty
+
+
+def step_cache_end(net, prefix):
+    """Unbind: forwards under `prefix` compute everything per call again (another model, another text)."""
+    hip._chk(hip.lib().fie_step_cache_bind(net.ctx.h, prefix.encode(), None, 0))
+
+
 # ---------------------------------------------------------------------------------------------------------------- a whole edit
 def register_pipeline(pipe):
-    """Every model of an fie_amd.pipe.HipImg2ImgPipeline under the prefixes of a diffusers pipeline directory."""
-    register_clip(pipe.clip_l, "text_encoder.")
-    register_clip(pipe.clip_g, "text_encoder_2.")
-    register_vae(pipe.vae)
-    register_unet(pipe.unet, "unet.")
-    register_controlnet(pipe.controlnet, "controlnet.")
+    """Every model of an fie_amd.pipe.HipImg2ImgPipeline under the prefixes of a diffusers pipeline directory ("text_encoder.", "unet.", ...), behind the
+    pipeline's own prefix (pipe.weight_prefix: several pipelines share one context's registry; the product path has registered its VAE and text encoders
+    there already)."""
+    pre = getattr(pipe, "weight_prefix", "")
+    if not getattr(pipe, "cpp_walks", False):
+        register_clip(pipe.clip_l, pre + "text_encoder.")
+        register_clip(pipe.clip_g, pre + "text_encoder_2.")
+        register_vae(pipe.vae, pre)
+    register_unet(pipe.unet, pre + "unet.")
+    register_controlnet(pipe.controlnet, pre + "controlnet.")
 
 
 @torch.no_grad()
-def run_edit(pipe, job):
+def run_edit(pipe, job, step_cache=True):
     """The device side of one edit (pipe.run_device's job, one image) with EVERY model call going through a C-ABI forward: the call sequence a
     non-Python host would issue for the pipeline call at /root/reference/src/pipeline.py:261-272.  Returns the u8 HWC image on the device."""
     ctx = pipe.ctx
@@ -315,8 +339,9 @@ def run_edit(pipe, job):
     nb, steps = job["nb"], job["steps"]
     lh, lw = h // 8, w // 8
     hw = lh * lw
-    pl, _ = clip_forward(pipe.clip_l, "text_encoder.", job["ids_l"])
-    pg, pooled = clip_forward(pipe.clip_g, "text_encoder_2.", job["ids_g"], job["eos_rows"])
+    pre = getattr(pipe, "weight_prefix", "")
+    pl, _ = clip_forward(pipe.clip_l, pre + "text_encoder.", job["ids_l"])
+    pg, pooled = clip_forward(pipe.clip_g, pre + "text_encoder_2.", job["ids_g"], job["eos_rows"])
     text = torch.cat([pl, pg], dim=1)
     moments = vae_encode(pipe.vae, ctx.pixels_in(job["img_u8"], True))
     sf = pipe.cfgs["vae"]["scaling_factor"]
@@ -325,12 +350,18 @@ def run_edit(pipe, job):
     ctx.latent_prep(moments, job["noises"][0], job["noises"][1], hw, sf, steps[0]["sqrt_ab"], steps[0]["sqrt_1mab"], latents, model_in)
     cond = ctx.pixels_in(job["ctl_u8"], False).repeat(nb, 1, 1, 1).contiguous()       # upstream runs the ControlNet on the duplicated control image
     decode_in = torch.empty((1, lh, lw, 8), device=dev, dtype=ctx.dtype)
+    if step_cache:                      # what does not change over the steps (text K / V, conditioning embedding) is computed by the first forward only
+        step_cache_begin(pipe.unet, pre + "unet.", nb, lh, lw, text.shape[0] // nb, False)
+        step_cache_begin(pipe.controlnet, pre + "controlnet.", nb, lh, lw, text.shape[0] // nb, True)
     next_noise = 2
     for st, t_dev in zip(steps, job["t_dev"]):
-        downs, mid = controlnet_forward(pipe.controlnet, "controlnet.", model_in, t_dev, text, pooled, job["time_ids"], cond, job["cn_scale"])
-        eps = unet_forward(pipe.unet, "unet.", model_in, t_dev, text, pooled, job["time_ids"], downs, mid)
+        downs, mid = controlnet_forward(pipe.controlnet, pre + "controlnet.", model_in, t_dev, text, pooled, job["time_ids"], cond, job["cn_scale"])
+        eps = unet_forward(pipe.unet, pre + "unet.", model_in, t_dev, text, pooled, job["time_ids"], downs, mid)
         z = None if st["last"] else job["noises"][next_noise]
         ctx.lcm_step(eps, nb, job["guidance"], latents, z, hw, st["sqrt_ab"], st["sqrt_1mab"], st["c_skip"], st["c_out"], st["sqrt_ab_prev"],
                      st["sqrt_1mab_prev"], model_in, 1.0 / sf, decode_in)
         next_noise += 1
+    if step_cache:
+        step_cache_end(pipe.unet, pre + "unet.")
+        step_cache_end(pipe.controlnet, pre + "controlnet.")
     return ctx.pixels_out(vae_decode(pipe.vae, decode_in))

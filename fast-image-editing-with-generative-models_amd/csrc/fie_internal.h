@@ -41,6 +41,7 @@ struct fie_program {
 };
 
 struct fie_weight { const void* ptr; int64_t n, ld; };    // fie_weights_register: a packed device tensor under its diffusers parameter name
+struct fie_step_cache { char* ptr; int64_t bytes; bool filled; };     // fie_step_cache_bind: what a model keeps over the denoising steps of one image
 
 struct fie_tile_override { int mode, M, N, K, code; };   // tuning hook: per-shape GEMM / conv tile code (mode 0 GEMM, 1 conv)
 
@@ -82,6 +83,7 @@ struct fie_ctx {
     std::vector<std::string>* oplog = nullptr;        // fie_debug_oplog: one line per launch (kernel symbol, grid, block, LDS, the op's own description)
     char op_desc[192] = "";                           // FIE_DESC: description of the op whose next launch is logged (consumed by that launch)
     std::map<std::string, fie_program*> graphs;       // fie_graph_register: "unet_forward", "vae_decode", ...
+    std::map<std::string, fie_step_cache> step_caches;   // by model prefix (graphs.cpp)
     std::map<std::string, fie_weight> weights;        // fie_weights_register: what the C++ graph walks (graphs.cpp: fie_vae_decode_f16) look up
 };
 

@@ -84,6 +84,21 @@ struct Walk {
     Arena arena;
     int rc = FIE_OK;
     bool plan_fused = true;     // plan mode: size the walk WITH the optional fused matrices (the entry takes the max of both plans)
+    // step cache (fie_step_cache_bind): tensors that do not change over the denoising steps of one image -- every transformer block's text K / V, the
+    // ControlNet's conditioning embedding -- live in a caller-owned buffer in walk order; the first forward after a bind / reset fills it, later ones read it
+    char* cache = nullptr;      // NULL: no cache bound (every call computes them in the workspace, as round 3 did)
+    int64_t cache_cap = 0, cache_cur = 0;
+    bool cache_fill = false, cache_count = false;      // cache_count: plan mode of fie_unet_step_cache_bytes
+    bool cached() const { return cache != nullptr || cache_count; }
+    T cache_slot(int64_t rows, int c) {
+        T t;
+        t.rows = rows; t.c = c;
+        const int64_t bytes = fie_roundup(rows * c * 2, 256);
+        if (!cache_count && cache_cur + bytes > cache_cap && rc == FIE_OK) { fie_set_error("%s: step cache too small (fie_unet_step_cache_bytes)", who); rc = FIE_EINVAL; }
+        t.ext = cache_count || !ok() ? reinterpret_cast<void*>(1) : static_cast<void*>(cache + cache_cur);
+        cache_cur += bytes;
+        return t;
+    }
     Walk(fie_ctx* c, const char* w, const char* pre, void* ws, int64_t cap) : ctx(c), who(w), prefix(pre ? pre : ""), base(static_cast<char*>(ws)), arena(cap) {}
     bool plan() const { return ctx == nullptr; }
     bool ok() const { return rc == FIE_OK; }
@@ -444,7 +459,13 @@ T unet_tblock(Walk& s, Cond& c, const std::string& p, T h, int tokens) {
     y = s.lnorm(p + "norm2", h1, 1e-5f);
     T q = s.linear(p + "attn2.to_q", y, C);
     s.free(y);
-    T kv = s.linear(p + "attn2.to_kv", c.text, 2 * C);
+    T kv;                                                    // K / V of the text: the same at every denoising step of an image
+    if (s.cached()) {
+        kv = s.cache_slot(c.text.rows, 2 * C);
+        if (s.cache_fill) s.linear(p + "attn2.to_kv", c.text, 2 * C, FIE_ACT_NONE, nullptr, 1.f, nullptr, nullptr, 0, 0, &kv);
+    } else {
+        kv = s.linear(p + "attn2.to_kv", c.text, 2 * C);
+    }
     a = s.attention(q, 0, kv, 0, kv, C, B, heads, hd, tokens, cfg->text_len);
     s.free(q);
     s.free(kv);
@@ -567,17 +588,22 @@ void controlnet_walk(Walk& s, const fie_unet_config* cfg, const void* x, const f
     // conditioning embedding (controlnet.py ControlNetConditioningEmbedding): conv_in, (conv, stride-2 conv) pairs, conv_out; SiLU between
     const int nc = cfg->num_cond_channels;
     int H = h << (nc - 1), W = w << (nc - 1);
-    T ci = Walk::ext(cond, (int64_t)B * H * W, 8);
-    T e = s.conv("controlnet_cond_embedding.conv_in", ci, B, H, W, cfg->cond_channels[0], 0, 1, 0, FIE_ACT_SILU);
-    for (int i = 0; i + 1 < nc; ++i) {
-        T e1 = s.conv("controlnet_cond_embedding.blocks." + std::to_string(2 * i), e, B, H, W, cfg->cond_channels[i], 0, 1, 0, FIE_ACT_SILU);
+    T ce;                                                    // the embedding of the edge map does not depend on the timestep: step cache
+    if (s.cached()) ce = s.cache_slot((int64_t)B * h * w, ch0);
+    if (!s.cached() || s.cache_fill) {
+        T ci = Walk::ext(cond, (int64_t)B * H * W, 8);
+        T e = s.conv("controlnet_cond_embedding.conv_in", ci, B, H, W, cfg->cond_channels[0], 0, 1, 0, FIE_ACT_SILU);
+        for (int i = 0; i + 1 < nc; ++i) {
+            T e1 = s.conv("controlnet_cond_embedding.blocks." + std::to_string(2 * i), e, B, H, W, cfg->cond_channels[i], 0, 1, 0, FIE_ACT_SILU);
+            s.free(e);
+            e = s.conv("controlnet_cond_embedding.blocks." + std::to_string(2 * i + 1), e1, B, H, W, cfg->cond_channels[i + 1], 0, 2, 0, FIE_ACT_SILU);
+            s.free(e1);
+            H /= 2; W /= 2;
+        }
+        if (s.cached()) s.conv("controlnet_cond_embedding.conv_out", e, B, H, W, ch0, 0, 1, 0, FIE_ACT_NONE, nullptr, nullptr, 0, &ce);
+        else ce = s.conv("controlnet_cond_embedding.conv_out", e, B, H, W, ch0);
         s.free(e);
-        e = s.conv("controlnet_cond_embedding.blocks." + std::to_string(2 * i + 1), e1, B, H, W, cfg->cond_channels[i + 1], 0, 2, 0, FIE_ACT_SILU);
-        s.free(e1);
-        H /= 2; W /= 2;
     }
-    T ce = s.conv("controlnet_cond_embedding.conv_out", e, B, H, W, ch0);
-    s.free(e);
     // sample = conv_in(x) + cond_embedding, then the encoder half shared with the UNet
     T xin = Walk::ext(x, (int64_t)B * h * w, 8);
     T x0 = s.conv("conv_in", xin, B, h, w, ch0, 0, 1, 0, FIE_ACT_NONE, &ce);
@@ -641,17 +667,31 @@ void unet_walk(Walk& s, const fie_unet_config* cfg, const void* x, const float* 
 
 constexpr int64_t kPlanCap = (int64_t)1 << 46;
 
-// The high-water mark of a walk, sized for a host that registered the optional fused matrices and for one that did not (the larger of the two;
-// a host that registered only some of them gets a loud "workspace too small" in the unlikely case first-fit packs that mix worse than both).
+// the step cache bound for this model prefix, if any: the walk fills it on the first forward after a bind / reset and reads it afterwards
+fie_step_cache* attach_cache(Walk& s, fie_ctx* ctx, const char* prefix) {
+    auto it = ctx->step_caches.find(prefix ? prefix : "");
+    if (it == ctx->step_caches.end()) return nullptr;
+    s.cache = it->second.ptr;
+    s.cache_cap = it->second.bytes;
+    s.cache_fill = !it->second.filled;
+    return &it->second;
+}
+
+// The high-water mark of a walk, sized for a host that registered the optional fused matrices and for one that did not, with and without a step
+// cache (the largest of the six; a host that registered only SOME of the fused matrices gets a loud "workspace too small" in the unlikely case
+// first-fit packs that mix worse than all of them).
 template <class F>
 int64_t plan_both(const char* who, F&& walk) {
     int64_t high = 0;
-    for (int fused = 0; fused < 2; ++fused) {
-        Walk s(nullptr, who, "", nullptr, kPlanCap);
-        s.plan_fused = fused != 0;
-        walk(s);
-        if (s.arena.high > high) high = s.arena.high;
-    }
+    for (int fused = 0; fused < 2; ++fused)
+        for (int cache = 0; cache < 3; ++cache) {            // no step cache / the call that fills it / a call that reads it: three allocation sequences
+            Walk s(nullptr, who, "", nullptr, kPlanCap);
+            s.plan_fused = fused != 0;
+            s.cache_count = cache != 0;
+            s.cache_fill = cache == 1;
+            walk(s);
+            if (s.arena.high > high) high = s.arena.high;
+        }
     return high;
 }
 
@@ -662,6 +702,13 @@ extern "C" {
 int fie_weights_register(fie_ctx* ctx, const char* name, const void* ptr, int64_t n, int64_t ld) {
     FIE_REQUIRE(ctx && name && ptr && n > 0 && ld >= 0, "fie_weights_register: bad argument");
     ctx->weights[name] = fie_weight{ptr, n, ld};
+    return FIE_OK;
+}
+
+int fie_weights_clear_prefix(fie_ctx* ctx, const char* prefix) {
+    FIE_REQUIRE(ctx && prefix, "fie_weights_clear_prefix: bad argument");
+    const std::string pre(prefix);
+    for (auto it = ctx->weights.lower_bound(pre); it != ctx->weights.end() && it->first.compare(0, pre.size(), pre) == 0;) it = ctx->weights.erase(it);
     return FIE_OK;
 }
 
@@ -683,7 +730,7 @@ int fie_vae_decode_f16(fie_ctx* ctx, const fie_vae_config* cfg, const void* z, v
     const char* who = "fie_vae_decode_f16";
     FIE_REQUIRE(ctx && cfg && z && out && workspace, "%s: NULL argument", who);
     FIE_REQUIRE(vae_cfg_ok(cfg), "%s: bad config", who);
-    Walk s(ctx, who, "", workspace, workspace_bytes);
+    Walk s(ctx, who, cfg->prefix, workspace, workspace_bytes);
     vae_decode_walk(s, cfg, z, out);
     return s.rc;
 }
@@ -697,7 +744,7 @@ int fie_vae_encode_f16(fie_ctx* ctx, const fie_vae_config* cfg, const void* x, v
     const char* who = "fie_vae_encode_f16";
     FIE_REQUIRE(ctx && cfg && x && moments && workspace, "%s: NULL argument", who);
     FIE_REQUIRE(vae_cfg_ok(cfg), "%s: bad config", who);
-    Walk s(ctx, who, "", workspace, workspace_bytes);
+    Walk s(ctx, who, cfg->prefix, workspace, workspace_bytes);
     vae_encode_walk(s, cfg, x, moments);
     return s.rc;
 }
@@ -738,8 +785,35 @@ int fie_unet_forward_f16(fie_ctx* ctx, const fie_unet_config* cfg, const char* p
     if (down_residuals)
         for (int i = 0; i < unet_num_skips(cfg); ++i) FIE_REQUIRE(down_residuals[i] != nullptr, "%s: down residual %d is NULL", who, i);
     Walk s(ctx, who, prefix, workspace, workspace_bytes);
+    fie_step_cache* sc = attach_cache(s, ctx, prefix);
     unet_walk(s, cfg, x, t, text, pooled, time_ids, down_residuals, mid_residual, eps_out);
+    if (sc && s.ok()) sc->filled = true;
     return s.rc;
+}
+
+// ---- step cache
+int64_t fie_unet_step_cache_bytes(const fie_unet_config* cfg, int controlnet) {
+    if (!unet_cfg_ok(cfg) || (controlnet && (cfg->num_cond_channels < 1 || cfg->num_cond_channels > 8))) return -1;
+    Walk s(nullptr, "fie_unet_step_cache_bytes", "", nullptr, kPlanCap);
+    s.cache_count = true;
+    if (controlnet) controlnet_walk(s, cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, nullptr);
+    else unet_walk(s, cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    return s.cache_cur;
+}
+
+int fie_step_cache_bind(fie_ctx* ctx, const char* prefix, void* ptr, int64_t bytes) {
+    FIE_REQUIRE(ctx && prefix && (ptr == nullptr || bytes > 0), "fie_step_cache_bind: bad argument");
+    if (!ptr) { ctx->step_caches.erase(prefix); return FIE_OK; }
+    ctx->step_caches[prefix] = fie_step_cache{static_cast<char*>(ptr), bytes, false};
+    return FIE_OK;
+}
+
+int fie_step_cache_reset(fie_ctx* ctx, const char* prefix) {
+    FIE_REQUIRE(ctx && prefix, "fie_step_cache_reset: bad argument");
+    auto it = ctx->step_caches.find(prefix);
+    FIE_REQUIRE(it != ctx->step_caches.end(), "fie_step_cache_reset: no step cache bound for '%s'", prefix);
+    it->second.filled = false;
+    return FIE_OK;
 }
 
 int64_t fie_controlnet_workspace_bytes(const fie_unet_config* cfg) {
@@ -756,7 +830,9 @@ int fie_controlnet_forward_f16(fie_ctx* ctx, const fie_unet_config* cfg, const c
     FIE_REQUIRE(unet_cfg_ok(cfg) && cfg->num_cond_channels >= 1 && cfg->num_cond_channels <= 8, "%s: bad config", who);
     for (int i = 0; i < unet_num_skips(cfg); ++i) FIE_REQUIRE(down_out[i] != nullptr, "%s: down output %d is NULL", who, i);
     Walk s(ctx, who, prefix, workspace, workspace_bytes);
+    fie_step_cache* sc = attach_cache(s, ctx, prefix);
     controlnet_walk(s, cfg, x, t, text, pooled, time_ids, cond, conditioning_scale, down_out, mid_out);
+    if (sc && s.ok()) sc->filled = true;
     return s.rc;
 }
 

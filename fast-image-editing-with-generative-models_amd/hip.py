@@ -62,6 +62,10 @@ SIGNATURES = {
     "fie_attention_f16_o8": [_P, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I, _F],
     "fie_quantize_f8": [_P, _P, _L, _P, _L, _L, _I, _F],
     "fie_amax_f16": [_P, _P, _L, _L, _I, _P],
+    "fie_weights_clear_prefix": [_P, _c.c_char_p],
+    "fie_step_cache_bind": [_P, _c.c_char_p, _P, _L],
+    "fie_step_cache_reset": [_P, _c.c_char_p],
+    "fie_unet_step_cache_bytes": [_P, _I],
     "fie_groupnorm_nhwc_f16_o8": [_P, _P, _I, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _F],
     "fie_groupnorm_stats_nhwc_f16_o8": [_P, _P, _I, _P, _I, _L, _I, _P, _P, _F, _I, _P, _P, _I, _F],
     "fie_conv3x3_x8_nhwc_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _F, _P, _L, _I, _P, _P, _L, _P, _L, _F, _I],
@@ -143,7 +147,8 @@ def lib():
             fn = getattr(_lib, name)
             fn.argtypes = args
             fn.restype = _L if name in ("fie_groupnorm_workspace_bytes", "fie_canny_workspace_bytes", "fie_time_embed_workspace_bytes", "fie_gn_stats_bytes", "fie_debug_oplog_read", "fie_vae_decode_workspace_bytes",
-                                       "fie_vae_encode_workspace_bytes", "fie_clip_text_workspace_bytes", "fie_unet_workspace_bytes", "fie_controlnet_workspace_bytes") else _I
+                                       "fie_vae_encode_workspace_bytes", "fie_clip_text_workspace_bytes", "fie_unet_workspace_bytes", "fie_controlnet_workspace_bytes",
+                                       "fie_unet_step_cache_bytes") else _I
         _lib.fie_last_error.restype = ctypes.c_char_p
         _lib.fie_last_error.argtypes = []
         _lib.fie_debug_last_gemm_kernel.restype = ctypes.c_char_p
@@ -175,7 +180,7 @@ GRAPH_NAMES = ("unet_forward", "controlnet_forward", "vae_encode", "vae_decode",
 class VaeConfig(ctypes.Structure):
     """include/fie.h: fie_vae_config (the C++ decoder walk, csrc/graphs.cpp)."""
     _fields_ = [("latent_h", _I), ("latent_w", _I), ("num_blocks", _I), ("block_out_channels", _I * 8), ("layers_per_block", _I),
-                ("norm_num_groups", _I), ("norm_eps", _F), ("out_channels", _I)]
+                ("norm_num_groups", _I), ("norm_eps", _F), ("out_channels", _I), ("prefix", ctypes.c_char_p)]
 
 
 class ClipConfig(ctypes.Structure):

@@ -2,6 +2,7 @@
 StableDiffusionXLControlNetImg2ImgPipeline call at /root/reference/src/pipeline.py:261-272, but every stage
 (CLIP text, VAE encode, ControlNet + UNet evaluations, CFG + LCM step, VAE decode, pixel conversion) runs in the
 hand-written HIP kernels of csrc/ (call order: SURVEY.md 3.2 steps 1-9)."""
+import itertools
 import os
 import threading
 import types
@@ -10,7 +11,7 @@ import numpy as np
 import torch
 from PIL import Image
 
-from . import hip
+from . import cabi, hip
 from .clip import ClipText, eos_positions
 from .lcm import LCMSchedule
 from .nn import ControlNet, UNet
@@ -19,6 +20,7 @@ from .tokenizer import StandInTokenizer
 from .vae import VAE
 
 F16 = torch.float16
+_PIPE_SEQ = itertools.count()
 
 
 class HipImg2ImgPipeline:
@@ -45,6 +47,15 @@ class HipImg2ImgPipeline:
         self.vae = VAE(ctx, cfgs["vae"], sds["vae"])
         self.clip_l = ClipText(ctx, cfgs["clip_l"], sds["clip_l"])
         self.clip_g = ClipText(ctx, cfgs["clip_g"], sds["clip_g"])
+        # The VAE and the two text encoders run through the C++ graph walks of the library (include/fie.h: fie_vae_encode_f16, fie_vae_decode_f16,
+        # fie_clip_text_forward_f16; csrc/graphs.cpp) -- bit-identical to the Python walks of vae.py / clip.py (tests/test_cabi_graphs_gpu.py), which stay as
+        # the weight packers and the A/B (FIE_CPP_WALKS=0).  Weights are registered under a prefix of this pipeline's own: contexts are shared.
+        self.weight_prefix = f"pipe{next(_PIPE_SEQ)}."
+        self.cpp_walks = (not ctx.f32) and ctx.device.type == "cuda" and os.environ.get("FIE_CPP_WALKS", "1") != "0"
+        if self.cpp_walks:
+            cabi.register_vae(self.vae, self.weight_prefix)
+            cabi.register_clip(self.clip_l, self.weight_prefix + "text_encoder.")
+            cabi.register_clip(self.clip_g, self.weight_prefix + "text_encoder_2.")
         self.tok_l, self.tok_g = tokenizers or (StandInTokenizer(cfgs["clip_l"]["pad_token_id"]),
                                                 StandInTokenizer(cfgs["clip_g"]["pad_token_id"]))
         self.scheduler = LCMSchedule(**(sched_cfg or LCM_SCHED))
@@ -83,6 +94,13 @@ class HipImg2ImgPipeline:
                 with torch.cuda.stream(st):
                     torch.zeros(1, device=ctx.device)
             torch.cuda.synchronize(ctx.device)
+
+    def __del__(self):
+        try:                       # the registry holds raw pointers into this pipeline's weight tensors: forget them with the pipeline
+            if getattr(self, "cpp_walks", False) and self.ctx.h:
+                hip.lib().fie_weights_clear_prefix(self.ctx.h, self.weight_prefix.encode())
+        except Exception:
+            pass
 
     # -- diffusers API surface the reference touches
     def set_progress_bar_config(self, **kw):          # run_batch.py:157-158
@@ -213,8 +231,12 @@ class HipImg2ImgPipeline:
         ctls = job["ctl_u8"] if n > 1 else job["ctl_u8"][None]
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            pl, _ = self.clip_l(job["ids_l"])
-            pg, pooled = self.clip_g(job["ids_g"], eos_rows=job["eos_rows"])
+            if self.cpp_walks:
+                pl, _ = cabi.clip_forward(self.clip_l, self.weight_prefix + "text_encoder.", job["ids_l"])
+                pg, pooled = cabi.clip_forward(self.clip_g, self.weight_prefix + "text_encoder_2.", job["ids_g"], job["eos_rows"])
+            else:
+                pl, _ = self.clip_l(job["ids_l"])
+                pg, pooled = self.clip_g(job["ids_g"], eos_rows=job["eos_rows"])
             text = torch.cat([pl, pg], dim=1)
             # 6. per-image invariants: nothing here depends on the latents, so the whole block rides on the side stream beside the VAE
             # encode (text-time addition embeddings, the ControlNet's edge-map embedding, the first step's timestep projections)
@@ -236,7 +258,7 @@ class HipImg2ImgPipeline:
         sf = self.cfgs["vae"]["scaling_factor"]
         for i in range(n):
             x_img = ctx.pixels_in(imgs[i], True)
-            moments, _ = self.vae.encode_moments(x_img)
+            moments = cabi.vae_encode(self.vae, x_img) if self.cpp_walks else self.vae.encode_moments(x_img)[0]
             ctx.latent_prep(moments, job["noises"][i * per], job["noises"][i * per + 1], hw, sf, steps[0]["sqrt_ab"],
                             steps[0]["sqrt_1mab"], latents[i], model_in[i * nb:(i + 1) * nb])
         next_noise = 2
@@ -267,7 +289,8 @@ class HipImg2ImgPipeline:
             next_noise += 1
             self._mark("lcm_step")
         # 8-9. decode + postprocess
-        outs = [ctx.pixels_out(self.vae.decode(decode_in[i:i + 1])) for i in range(n)]
+        dec = (lambda z: cabi.vae_decode(self.vae, z)) if self.cpp_walks else self.vae.decode
+        outs = [ctx.pixels_out(dec(decode_in[i:i + 1])) for i in range(n)]
         out_u8 = outs[0] if n == 1 else torch.stack(outs)
         self._mark("vae_decode")
         self.last_stats = dict(unet_evals=len(steps), cfg_batch=nb, latent_hw=(lh, lw), images=n)

@@ -103,6 +103,7 @@ typedef struct fie_vae_config {
     int norm_num_groups;           /* 32 */
     float norm_eps;                /* 1e-6 */
     int out_channels;              /* 3 */
+    const char* prefix;            /* the weights were registered as "<prefix>encoder....", "<prefix>post_quant_conv", ...; NULL: no prefix */
 } fie_vae_config;
 typedef struct fie_clip_config {
     int batch, tokens;             /* ids: int32 [batch * tokens] on the device */
@@ -133,6 +134,7 @@ typedef struct fie_unet_config {   /* UNet2DConditionModel (SDXL family) and the
 } fie_unet_config;
 int fie_weights_register(fie_ctx* ctx, const char* name, const void* ptr, int64_t n, int64_t ld);
 int fie_weights_clear(fie_ctx* ctx);
+int fie_weights_clear_prefix(fie_ctx* ctx, const char* prefix);     /* forgets every name that starts with prefix (a model that goes away) */
 /* AutoencoderKL.decode(latents / scaling_factor): z [1, h, w, 8] -> out [1, 8 h, 8 w, 4];  names "post_quant_conv", "decoder...." */
 int64_t fie_vae_decode_workspace_bytes(const fie_vae_config* cfg, int latent_h, int latent_w);
 int fie_vae_decode_f16(fie_ctx* ctx, const fie_vae_config* cfg, const void* z, void* out, void* workspace, int64_t workspace_bytes);
@@ -158,6 +160,16 @@ int64_t fie_controlnet_workspace_bytes(const fie_unet_config* cfg);
 int fie_controlnet_forward_f16(fie_ctx* ctx, const fie_unet_config* cfg, const char* prefix, const void* x, const float* t, const void* text, const void* pooled,
                                const float* time_ids, const void* cond, float conditioning_scale, void* const* down_out, void* mid_out, void* workspace,
                                int64_t workspace_bytes);
+/* Step cache (optional): what a UNet / ControlNet forward computes from inputs that do NOT change over the denoising steps of one image -- the cross-
+ * attention K / V of the text in every transformer block (upstream attention_processor.py: to_k / to_v of encoder_hidden_states) and the ControlNet's
+ * conditioning embedding of the edge map -- kept in a caller-owned device buffer bound to the context under the model's prefix.  The first
+ * fie_unet_forward_f16 / fie_controlnet_forward_f16 with that prefix after a bind or a reset FILLS the buffer (and ignores nothing: results are the
+ * same bits), every later one READS it and skips those launches (SSD-1B: ~60 small GEMMs per UNet call, seven convs per ControlNet call).  The host
+ * resets at every new image (new text / edge map); text, cond and the batch must stay what they were at the fill.  The decision is taken on the host when
+ * the call is issued, so a hipGraph captured over a whole edit (reset, N x forwards) replays correctly.  Without a bound cache every call computes them. */
+int64_t fie_unet_step_cache_bytes(const fie_unet_config* cfg, int controlnet);
+int fie_step_cache_bind(fie_ctx* ctx, const char* prefix, void* ptr, int64_t bytes);     /* ptr NULL: unbind */
+int fie_step_cache_reset(fie_ctx* ctx, const char* prefix);
 /* the two element-wise helpers the walks need (also plain ops): out = a + b over n f16 values (n % 8 == 0); a strided row copy (cols % 8 == 0) */
 int fie_add_f16(fie_ctx* ctx, const void* a, const void* b, void* out, int64_t n);
 int fie_copy_rows_f16(fie_ctx* ctx, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols);

@@ -28,7 +28,7 @@ def test_vae_decode_and_encode_walked_in_cpp(fie, stack_name, lat):
     z[..., :4] = torch.randn(1, lat, lat, 4, generator=g).half()
     zd = z.to(fie.device)
     ref = vae.decode(zd).float()
-    cabi.register_vae(vae)
+    cabi.register_vae(vae, f"vae_{stack_name}.")       # a prefix of this test's own: the session's context also serves the product pipelines' walks
     out = cabi.vae_decode(vae, zd)
     assert out.shape == ref.shape
     err = _rel(out, ref)
@@ -65,12 +65,12 @@ def test_vae_decode_and_encode_walked_in_cpp(fie, stack_name, lat):
         torch.cuda.synchronize()
         assert torch.equal(cap, cabi.vae_decode(vae, zd * 0.5))
         # a short workspace and a weight that was never registered: FIE_EINVAL with the reason, nothing launched past it
-        vc = cabi.vae_config(cfgs["vae"], lat, lat)
+        vc = cabi.vae_config(cfgs["vae"], lat, lat, f"vae_{stack_name}.")
         need = hip.lib().fie_vae_decode_workspace_bytes(ctypes.byref(vc), lat, lat)
         ws = torch.empty(need, device=fie.device, dtype=torch.uint8)
         with pytest.raises(hip.FieError, match="workspace too small"):
             hip._chk(hip.lib().fie_vae_decode_f16(fie.h, ctypes.byref(vc), zd.data_ptr(), out.data_ptr(), ws.data_ptr(), need // 4))
-        hip._chk(hip.lib().fie_weights_clear(fie.h))
+        hip._chk(hip.lib().fie_weights_clear_prefix(fie.h, f"vae_{stack_name}.".encode()))
         with pytest.raises(hip.FieError, match="post_quant_conv.weight"):
             cabi.vae_decode(vae, zd)
 
@@ -165,6 +165,31 @@ def test_controlnet_and_unet_walked_in_cpp(fie, stack_name, lat):
     eps0 = cabi.unet_forward(unet, "unet.", x, t, text, pooled, tid)
     eps0_ref = unet.decode(mid, skips, tb_u, text, 77)
     assert _rel(eps0, eps0_ref) < 1e-2
+    # step cache (include/fie.h: fie_step_cache_bind): the first forward after a bind fills it with the text K / V of every transformer block (ControlNet:
+    # and the conditioning embedding), the next ones read it -- the same bits as computing them per call, at another timestep too; unbound again afterwards
+    b_, lh_, lw_, _ = x.shape
+    cabi.step_cache_begin(unet, "unet.", b_, lh_, lw_, 77, False)
+    cabi.step_cache_begin(cn, "controlnet.", b_, lh_, lw_, 77, True)
+    try:
+        fill = cabi.unet_forward(unet, "unet.", x, t, text, pooled, tid)
+        t2 = t * 0.5
+        hit = cabi.unet_forward(unet, "unet.", x, t2, text, pooled, tid)
+        dfill, mfill = cabi.controlnet_forward(cn, "controlnet.", x, t, text, pooled, tid, cond, scale)
+        dhit, mhit = cabi.controlnet_forward(cn, "controlnet.", x, t2, text, pooled, tid, cond, scale)
+    finally:
+        cabi.step_cache_end(unet, "unet.")
+        cabi.step_cache_end(cn, "controlnet.")
+    assert torch.equal(fill, eps0) and all(torch.equal(a_, b_) for a_, b_ in zip(dfill + [mfill], downs + [midr]))
+    assert torch.equal(hit, cabi.unet_forward(unet, "unet.", x, t2, text, pooled, tid))
+    dref, mref2 = cabi.controlnet_forward(cn, "controlnet.", x, t2, text, pooled, tid, cond, scale)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(dhit + [mhit], dref + [mref2]))
+    short = torch.empty(1024, device=x.device, dtype=torch.uint8)
+    hip._chk(hip.lib().fie_step_cache_bind(fie.h, b"unet.", short.data_ptr(), short.numel()))
+    try:
+        with pytest.raises(hip.FieError, match="step cache too small"):
+            cabi.unet_forward(unet, "unet.", x, t, text, pooled, tid)
+    finally:
+        cabi.step_cache_end(unet, "unet.")
     if stack_name == "tiny":
         from oracle import nets
         f32 = lambda sd: {k: v.float() for k, v in sd.items()}
