@@ -404,6 +404,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    fp8_scales = None
+    if args.weights == "f8e4m3":
+        # config 5 runs with CALIBRATED activation scales (one eager edit on the first item: per-tensor amax -> power-of-two scale, pipe.calibrate_fp8)
+        img0 = work[0][0].resize((1024, 1024))
+        sc = pipe.calibrate_fp8(prompt=work[0][1], image=img0, control_image=editor.preprocess_image(img0), negative_prompt="", strength=args.strength,
+                                num_inference_steps=4, guidance_scale=args.guidance, controlnet_conditioning_scale=0.5,
+                                generator=torch.Generator("cpu").manual_seed(42))
+        flat = [v for vs in sc.values() for v in vs]
+        fp8_scales = {"tensors": len(flat), "min": min(flat), "max": max(flat)}
+
     def edit(s):
         # exactly the call of run_batch.py:209-219 (PIL in -> PIL out: LANCZOS 1024^2, Canny, tokenise, RNG, H2D, CLIP x2, VAE
         # encode, evals x (ControlNet + UNet), CFG + LCM steps, VAE decode, u8, D2H); strength is the additive flag
@@ -555,7 +565,7 @@ def main():
                                    f"strength={args.strength}, guidance={args.guidance}, 1024x1024, batch=1 image per GPU, one edit at a time",
                        "unet_preset": cfgs["unet"]["name"], "controlnet_preset": cfgs["controlnet"]["name"],
                        "unet_evals": evals, "cfg_batch": nb, "parallelism": f"image-parallel x{world}",
-                       "launch": "eager" if args.no_graph else "hipGraph replay", "weights": args.weights,
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "weights": args.weights, "fp8_activation_scales": fp8_scales,
                        "tflop_per_image": round(fl["total"] / 1e12, 2)},
             # the dominant problem (top row of profiles/r04_per_shape_roofline.md), HIP-event timed above on cold weights; the second kernel,
             # the per-class table of the committed kernel trace and the whole UNet forward (every launch between the events bracketing

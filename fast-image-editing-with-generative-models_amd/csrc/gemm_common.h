@@ -191,50 +191,63 @@ __device__ __forceinline__ void epilogue_lean_scaled(const GemmArgs& p, f32x4 (&
 
 // The LEAN GEGLU epilogue of the big tiles (256x320: the FF1 projection): bias + value * gelu(gate) -> f16 pairs, nothing else compiled in; same
 // arithmetic as the full epilogue with scale 1.  The full path of these tiles inlines the generic epilogue three times.
-// Stores (round 4): a lane's two outputs of a fragment are 4 bytes, and 4-byte stores reach the fabric as partial sectors (round-3 PMC: WRITE_SIZE 55 MB for
-// the 21 MB output, 2.6x).  Four ROW fragments at a time, a 4x4 transpose of dwords across the four fq lane rows (two v_permlane16_swap + two
-// v_permlane32_swap) hands every lane the 16 CONTIGUOUS bytes one fragment column holds of one row: a 16-byte store per lane instead of four 4-byte ones.
+// Stores (round 4): a lane's two outputs of a fragment are 4 bytes; stored as they are, every instruction leaves 16 bytes in each of 16 rows and the
+// fabric sees partial sectors (round-3 PMC: WRITE_SIZE 55 MB for the 21 MB output, 2.6x).  A 4x4 transpose of dwords across the four fq lane rows (two
+// v_permlane16_swap + two v_permlane32_swap) regroups them: over four fragment COLUMNS lane row q ends up with the 16 contiguous bytes of column I0 + q, so
+// one 16-byte store per lane writes 64 contiguous bytes per row; the columns left over (FN % 4) are transposed over four ROW fragments instead (16-byte
+// stores, 16 bytes per row: fewer instructions, same sectors).
 template <int FM, int FN, int WM, int WN>
 __device__ __forceinline__ void epilogue_geglu_lean(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane) {
-    static_assert(FM % 4 == 0, "row fragments are transposed in fours");
+    static_assert(FM % 4 == 0, "left-over fragment columns are transposed over four row fragments");
     const int fr = lane & 15, fq = lane >> 4;
     const int mrow = m0 + wm * WM + fr, nbase = n0 + wn * WN;
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)(p.M - 1) * p.ldc + (p.N >> 1)) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.bias), 0, p.bias ? p.N * 2 : 0, 0x00020000);
-    u32x2 bnext = __builtin_amdgcn_raw_buffer_load_b64(rs_b, (unsigned)(nbase + fq * 4) * 2u, 0, 0);       // no bias: zero-size descriptor, reads zero
-    // after the transpose of row fragments 4 h .. 4 h + 3 this lane holds row fragment 4 h + fq: its row of the matrix
-    unsigned ro[FM / 4];
-#pragma unroll
-    for (int h = 0; h < FM / 4; ++h) {
-        const int m = mrow + (4 * h + fq) * 16;
-        ro[h] = m < p.M ? (unsigned)m * (unsigned)p.ldc * 2u : 0x80000000u;
-    }
-    static_for([&](auto ic) {
-        constexpr int I = decltype(ic)::value;
+    auto bias4 = [&](int i) { return __builtin_amdgcn_raw_buffer_load_b64(rs_b, (unsigned)(nbase + i * 16 + fq * 4) * 2u, 0, 0); };   // no bias: zero-size descriptor, reads zero
+    auto pair = [&](const f32x4& a, u32x2 bb) {
         f16x4 b;
-        __builtin_memcpy(&b, &bnext, 8);
-        if constexpr (I + 1 < FN) bnext = __builtin_amdgcn_raw_buffer_load_b64(rs_b, (unsigned)(nbase + (I + 1) * 16 + fq * 4) * 2u, 0, 0);      // one fragment column ahead: 160 accumulator registers leave no room for all five
-        const int n = nbase + I * 16;                          // the fragment column's first value / gate column: output column n / 2, two bytes each -> byte offset n
+        __builtin_memcpy(&b, &bb, 8);
+        f16x2 o;
+        o[0] = (half_t)((a[0] + (float)b[0]) * fie_gelu(a[1] + (float)b[1]) * 1.0f);
+        o[1] = (half_t)((a[2] + (float)b[2]) * fie_gelu(a[3] + (float)b[3]) * 1.0f);
+        unsigned bits;
+        __builtin_memcpy(&bits, &o, 4);
+        return bits;
+    };
+    auto transpose4 = [](unsigned& r0, unsigned& r1, unsigned& r2, unsigned& r3) {      // register k of lane row q <- register q of lane row k
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r0), "+v"(r1));
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r2), "+v"(r3));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r0), "+v"(r2));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r1), "+v"(r3));
+    };
+    auto rowoff = [&](int m) { return m < p.M ? (unsigned)m * (unsigned)p.ldc * 2u : 0x80000000u; };
+    // a value / gate column n is output column n / 2, two bytes each: byte offset n
+    static_for([&](auto gc) {                                 // four fragment columns at a time: this lane stores column I0 + fq
+        constexpr int I0 = 4 * decltype(gc)::value;
+        const u32x2 b0 = bias4(I0), b1 = bias4(I0 + 1), b2 = bias4(I0 + 2), b3 = bias4(I0 + 3);
+        const int nst = nbase + (I0 + fq) * 16;
+        const unsigned co = nst < p.N ? (unsigned)nst : 0xC0000000u;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            unsigned r0 = pair(acc[I0][j], b0), r1 = pair(acc[I0 + 1][j], b1), r2 = pair(acc[I0 + 2][j], b2), r3 = pair(acc[I0 + 3][j], b3);
+            transpose4(r0, r1, r2, r3);
+            const u32x4 v = {r0, r1, r2, r3};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, rowoff(mrow + j * 16) + co, 0, 0);
+        }
+    }, std::make_integer_sequence<int, FN / 4>{});
+    static_for([&](auto ic) {                                 // the columns left over: four row fragments at a time, this lane stores row fragment 4 h + fq
+        constexpr int I = FN / 4 * 4 + decltype(ic)::value;
+        const u32x2 b = bias4(I);
+        const int n = nbase + I * 16;
         const unsigned co = n < p.N ? (unsigned)n : 0xC0000000u;
-        auto pair = [&](const f32x4& a) {
-            f16x2 o;
-            o[0] = (half_t)((a[0] + (float)b[0]) * fie_gelu(a[1] + (float)b[1]) * 1.0f);
-            o[1] = (half_t)((a[2] + (float)b[2]) * fie_gelu(a[3] + (float)b[3]) * 1.0f);
-            unsigned bits;
-            __builtin_memcpy(&bits, &o, 4);
-            return bits;
-        };
 #pragma unroll
         for (int h = 0; h < FM / 4; ++h) {
-            unsigned r0 = pair(acc[I][4 * h]), r1 = pair(acc[I][4 * h + 1]), r2 = pair(acc[I][4 * h + 2]), r3 = pair(acc[I][4 * h + 3]);
-            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r0), "+v"(r1));
-            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(r2), "+v"(r3));
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r0), "+v"(r2));
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r1), "+v"(r3));
+            unsigned r0 = pair(acc[I][4 * h], b), r1 = pair(acc[I][4 * h + 1], b), r2 = pair(acc[I][4 * h + 2], b), r3 = pair(acc[I][4 * h + 3], b);
+            transpose4(r0, r1, r2, r3);
             const u32x4 v = {r0, r1, r2, r3};
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, ro[h] + co, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, rowoff(mrow + (4 * h + fq) * 16) + co, 0, 0);
         }
-    }, std::make_integer_sequence<int, FN>{});
+    }, std::make_integer_sequence<int, FN % 4>{});
 }
 
 // PATCH (conv_halo.hip only): the tile is a 16x16 output patch, fragment rows p.frag_ld = OW apart (GemmArgs::frag_ld); every other kernel compiles
