@@ -497,6 +497,7 @@ int fie_attn_init(void) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<64, 2, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * (int)sizeof(half_t));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<64, 1, 96>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 96 * 64 * (int)sizeof(half_t));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<64, 1, 64, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 64 * (int)sizeof(half_t));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<64, 1, 64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * (int)sizeof(half_t));
     if (e != hipSuccess) {
         fie_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return FIE_EHIP;
@@ -530,6 +531,7 @@ static int attention_impl(fie_ctx* ctx, const void* Q, int64_t ldq, const void* 
     if (ctx->attn_variant == 3) return launch_attn2<64, 1, 64>(ctx, a, B);      // A/B: 64 queries per block as 4 waves x 16 everywhere
     if (ctx->attn_variant == 4) return launch_attn2<64, 2, 64, 2>(ctx, a, B);   // A/B: 64 queries per block as TWO waves x 32 (half the LDS fragment reads per MFMA)
     if (ctx->attn_variant == 5) return launch_attn2<64, 1, 64, 4, 3>(ctx, a, B);   // A/B: three-stage K / V ring (two tiles ahead, counted vmcnt)
+    if (ctx->attn_variant == 6) return launch_attn2<64, 1, 64, 8>(ctx, a, B);      // A/B: 128 queries per block as EIGHT waves x 16 (one K / V tile fill serves twice the queries)
     // Round 3, whole UNet forward (profiles/r03_attention_block_forms_in_unet.log): 16 queries per wave everywhere 15.24 ms; 32 per wave for the
     // 4096-token maps (the round-2 rule) 15.40-15.44 ms, whether the small maps run 4 x 16 or 2 x 32 -- so 128-query blocks only for grids of
     // four and more waves of them (batched jobs), where the round-2 measurements were taken
@@ -555,7 +557,7 @@ extern "C" int fie_attention_f16_o8(fie_ctx* ctx, const void* Q, int64_t ldq, co
 }
 
 extern "C" int fie_debug_attn_variant(fie_ctx* ctx, int v) {
-    FIE_REQUIRE(ctx != nullptr && v >= 0 && v <= 5, "fie_debug_attn_variant: bad argument");
+    FIE_REQUIRE(ctx != nullptr && v >= 0 && v <= 6, "fie_debug_attn_variant: bad argument");
     ctx->attn_variant = v;
     return FIE_OK;
 }

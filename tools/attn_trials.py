@@ -20,7 +20,7 @@ pipe.run_device(job)
 torch.cuda.synchronize()
 for rnd in range(3):
     row = []
-    for v in (0, 5, 4, 2):
+    for v in (int(x) for x in (sys.argv[1:] or ['0', '5', '4', '2'])):
         hip.lib().fie_debug_attn_variant(ctx.h, v)
         row.append(f"variant {v}: {min(time_unet_forward(pipe, job, iters=4) for _ in range(2)):.3f} ms")
     print("  ".join(row), flush=True)
