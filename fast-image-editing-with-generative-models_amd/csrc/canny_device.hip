@@ -128,39 +128,82 @@ __global__ void canny_out_kernel(const uint8_t* map, size_t n, uint8_t* out) {
 
 extern "C" {
 
-int64_t fie_canny_workspace_bytes(int H, int W) { return (int64_t)H * W + 256; }
+int64_t fie_canny_workspace_bytes(int H, int W) { return (int64_t)H * W + 256; }     // the label map + the flag words of a round
+
+// One round of hysteresis = kPasses passes, each with its own flag word: the fixed point is reached when the LAST pass of a round changed nothing.
+// (Round 3 read ONE flag per round -- "any of the four passes changed something" -- so an image that needs two passes paid for eight and two read-backs.)
+constexpr int kPasses = 4;
+
+static int canny_round(fie_ctx* ctx, uint8_t* map, int H, int W, int* flags) {
+    if (hipMemsetAsync(flags, 0, kPasses * sizeof(int), ctx->stream) != hipSuccess) { fie_set_error("fie_canny_rgb_device_u8: memset failed"); return FIE_EHIP; }
+    const dim3 hgrid((W + HT - 1) / HT, (H + HT - 1) / HT);
+    for (int rep = 0; rep < kPasses; ++rep) fie_launch(ctx, canny_hyst_kernel, hgrid, dim3(256), 0, map, H, W, flags + rep);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
+
+static void canny_out(fie_ctx* ctx, const uint8_t* map, int H, int W, uint8_t* edges_rgb) {
+    const size_t n = (size_t)H * W;
+    fie_launch(ctx, canny_out_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, map, n, edges_rgb);
+}
+
+// Asynchronous first half: NMS, one round of hysteresis, the edge map of that state, and the round's flags on their way to `host_flags` (kPasses ints
+// of PINNED host memory).  Nothing is waited for: the host goes on with its own preparation while the device works.
+int fie_canny_rgb_device_begin_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int low, int high, void* workspace, uint8_t* edges_rgb, int* host_flags) {
+    FIE_REQUIRE(ctx && rgb && workspace && edges_rgb && host_flags && H > 0 && W > 0, "fie_canny_rgb_device_begin_u8: bad argument");
+    if (low > high) { int t = low; low = high; high = t; }
+    uint8_t* map = (uint8_t*)workspace;
+    int* flags = (int*)(map + (((size_t)H * W + 63) / 64) * 64);
+    fie_launch(ctx, canny_nms_kernel, dim3((W + TX - 1) / TX, (H + TY - 1) / TY), dim3(TX, TY), 0, rgb, H, W, low, high, map);
+    FIE_LAUNCH_CHECK();
+    const int rc = canny_round(ctx, map, H, W, flags);
+    if (rc != FIE_OK) return rc;
+    canny_out(ctx, map, H, W, edges_rgb);
+    FIE_LAUNCH_CHECK();
+    if (hipMemcpyAsync(host_flags, flags, kPasses * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+        fie_set_error("fie_canny_rgb_device_begin_u8: flag copy failed");
+        return FIE_EHIP;
+    }
+    return FIE_OK;
+}
+
+// Second half: waits for the first (SYNCHRONISES the ctx stream); when its last pass still changed something, further rounds until one ends unchanged, and
+// the edge map again.  iterations (optional): hysteresis passes launched in all.
+int fie_canny_rgb_device_finish_u8(fie_ctx* ctx, int H, int W, void* workspace, uint8_t* edges_rgb, int* host_flags, int* iterations) {
+    FIE_REQUIRE(ctx && workspace && edges_rgb && host_flags && H > 0 && W > 0, "fie_canny_rgb_device_finish_u8: bad argument");
+    uint8_t* map = (uint8_t*)workspace;
+    int* flags = (int*)(map + (((size_t)H * W + 63) / 64) * 64);
+    const int max_iters = ((W + HT - 1) / HT) * ((H + HT - 1) / HT) + 2 * kPasses;       // a strong seed can cross every tile at most once
+    int iters = kPasses;
+    bool more = false;
+    for (;;) {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { fie_set_error("fie_canny_rgb_device_finish_u8: synchronisation failed"); return FIE_EHIP; }
+        if (!host_flags[kPasses - 1]) break;
+        if (iters > max_iters) { fie_set_error("fie_canny_rgb_device_u8: hysteresis did not converge in %d passes", iters); return FIE_EHIP; }
+        more = true;
+        const int rc = canny_round(ctx, map, H, W, flags);
+        if (rc != FIE_OK) return rc;
+        if (hipMemcpyAsync(host_flags, flags, kPasses * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+            fie_set_error("fie_canny_rgb_device_finish_u8: flag copy failed");
+            return FIE_EHIP;
+        }
+        iters += kPasses;
+    }
+    if (more) {
+        canny_out(ctx, map, H, W, edges_rgb);
+        FIE_LAUNCH_CHECK();
+    }
+    if (iterations) *iterations = iters;
+    return FIE_OK;
+}
 
 int fie_canny_rgb_device_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int low, int high, void* workspace,
                             uint8_t* edges_rgb, int* iterations) {
     FIE_REQUIRE(ctx && rgb && workspace && edges_rgb && H > 0 && W > 0, "fie_canny_rgb_device_u8: bad argument");
-    if (low > high) { int t = low; low = high; high = t; }
-    uint8_t* map = (uint8_t*)workspace;
-    int* flag = (int*)(map + (((size_t)H * W + 63) / 64) * 64);
-    fie_launch(ctx, canny_nms_kernel, dim3((W + TX - 1) / TX, (H + TY - 1) / TY), dim3(TX, TY), 0, rgb, H, W, low, high, map);
-    FIE_LAUNCH_CHECK();
-    const dim3 hgrid((W + HT - 1) / HT, (H + HT - 1) / HT);
-    int iters = 0;
-    const int max_iters = (int)(hgrid.x * hgrid.y) + 4;       // a strong seed can cross every tile at most once
-    for (;;) {
-        int h = 0;
-        if (hipMemsetAsync(flag, 0, sizeof(int), ctx->stream) != hipSuccess) { fie_set_error("fie_canny_rgb_device_u8: memset failed"); return FIE_EHIP; }
-        for (int rep = 0; rep < 4; ++rep)                   // four passes per read-back: a pass past the fixed point changes nothing, a host round trip costs more than a pass
-            fie_launch(ctx, canny_hyst_kernel, hgrid, dim3(256), 0, map, H, W, flag);
-        FIE_LAUNCH_CHECK();
-        if (hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            fie_set_error("fie_canny_rgb_device_u8: flag read-back failed");
-            return FIE_EHIP;
-        }
-        iters += 4;
-        if (!h) break;
-        if (iters > max_iters) { fie_set_error("fie_canny_rgb_device_u8: hysteresis did not converge in %d passes", iters); return FIE_EHIP; }
-    }
-    const size_t n = (size_t)H * W;
-    fie_launch(ctx, canny_out_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, map, n, edges_rgb);
-    FIE_LAUNCH_CHECK();
-    if (iterations) *iterations = iters;
-    return FIE_OK;
+    int host_flags[kPasses] = {0, 0, 0, 0};               // pageable: the copy is then synchronous with respect to the host, which this entry is anyway
+    const int rc = fie_canny_rgb_device_begin_u8(ctx, rgb, H, W, low, high, workspace, edges_rgb, host_flags);
+    if (rc != FIE_OK) return rc;
+    return fie_canny_rgb_device_finish_u8(ctx, H, W, workspace, edges_rgb, host_flags, iterations);
 }
 
 }  // extern "C"

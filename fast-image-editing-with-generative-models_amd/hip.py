@@ -62,6 +62,8 @@ SIGNATURES = {
     "fie_attention_f16_o8": [_P, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I, _F],
     "fie_quantize_f8": [_P, _P, _L, _P, _L, _L, _I, _F],
     "fie_amax_f16": [_P, _P, _L, _L, _I, _P],
+    "fie_canny_rgb_device_begin_u8": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "fie_canny_rgb_device_finish_u8": [_P, _I, _I, _P, _P, _P, _P],
     "fie_weights_clear_prefix": [_P, _c.c_char_p],
     "fie_step_cache_bind": [_P, _c.c_char_p, _P, _L],
     "fie_step_cache_reset": [_P, _c.c_char_p],
@@ -818,6 +820,29 @@ class Context:
         out = torch.empty((h, w, 3), device=self.device, dtype=torch.uint8)
         it = _I(0)
         _chk(lib().fie_canny_rgb_device_u8(self.h, _p(rgb_u8), h, w, int(low), int(high), _p(ws), _p(out), ctypes.byref(it)))
+        self.canny_passes = it.value
+        return out
+
+    def canny_begin(self, rgb_u8, low=100, high=200):
+        """First half of canny_device() (include/fie.h: fie_canny_rgb_device_begin_u8): launches everything and returns (edge map tensor, state) without
+        waiting; the tensor's contents are final once canny_finish(state) has returned."""
+        self.sync_stream()
+        h, w, _ = rgb_u8.shape
+        assert rgb_u8.is_contiguous() and rgb_u8.dtype == torch.uint8
+        ws = torch.empty(lib().fie_canny_workspace_bytes(h, w), device=self.device, dtype=torch.uint8)
+        out = torch.empty((h, w, 3), device=self.device, dtype=torch.uint8)
+        cache = self.__dict__.setdefault("_canny_flags", {})           # pinned flag words, one set per stream (edits in flight run on their own)
+        flags = cache.get(self._stream)
+        if flags is None:
+            flags = cache[self._stream] = torch.zeros(4, dtype=torch.int32).pin_memory()
+        _chk(lib().fie_canny_rgb_device_begin_u8(self.h, _p(rgb_u8), h, w, int(low), int(high), _p(ws), _p(out), flags.data_ptr()))
+        return out, (h, w, ws, out, flags, rgb_u8)
+
+    def canny_finish(self, state):
+        h, w, ws, out, flags, _src = state
+        self.sync_stream()
+        it = _I(0)
+        _chk(lib().fie_canny_rgb_device_finish_u8(self.h, h, w, _p(ws), _p(out), flags.data_ptr(), ctypes.byref(it)))
         self.canny_passes = it.value
         return out
 

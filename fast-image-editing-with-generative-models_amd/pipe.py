@@ -500,16 +500,18 @@ class HipImg2ImgPipeline:
 
     def __call__(self, prompt, negative_prompt="", image=None, control_image=None, strength=0.8,
                  num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5, generator=None,
-                 output_type="pil", slot=0, **unused):
+                 output_type="pil", slot=0, pre_run=None, **unused):
         """`slot` (additive): independent hipGraph instance + stream, so that several calls may be in flight from different
-        host threads on one GPU (graph mode only)."""
+        host threads on one GPU (graph mode only).  `pre_run` (additive): a callable run on the slot's stream after the host-side
+        preparation and before the device job is issued -- FastEditor.edit() finishes its asynchronous device Canny there, so the
+        tokeniser / RNG / uploads of prepare() overlap the Canny kernels instead of following them."""
         if slot and not self.use_graph:
             raise ValueError("slots > 0 need hipGraph replay (the eager path shares per-image state)")
         caller, st = torch.cuda.current_stream(self.ctx.device), self.slot_stream(slot)
         st.wait_stream(caller)                           # device-resident inputs may still be in flight on the caller's stream
         with torch.cuda.stream(st):
             out = self._call(prompt, negative_prompt, image, control_image, strength, num_inference_steps, guidance_scale,
-                             controlnet_conditioning_scale, generator, output_type, slot)
+                             controlnet_conditioning_scale, generator, output_type, slot, pre_run)
         caller.wait_stream(st)
         return out
 
@@ -527,11 +529,13 @@ class HipImg2ImgPipeline:
         return host.numpy().copy()
 
     def _call(self, prompt, negative_prompt, image, control_image, strength, num_inference_steps, guidance_scale,
-              controlnet_conditioning_scale, generator, output_type, slot):
+              controlnet_conditioning_scale, generator, output_type, slot, pre_run=None):
         if isinstance(prompt, (list, tuple)):            # [additive] a batch: lists of prompts / images / generators
             job = self.prepare_batch(list(prompt), negative_prompt if isinstance(negative_prompt, (list, tuple)) else None,
                                      list(image), list(control_image), strength, num_inference_steps, guidance_scale,
                                      controlnet_conditioning_scale, generator if isinstance(generator, (list, tuple)) else None)
+            if pre_run is not None:
+                pre_run()
             out_u8 = self.run_device_graphed(job, slot) if self.use_graph else self._run_eager(job)
             arr = self._to_host(out_u8, slot)
             arr = arr[None] if arr.ndim == 3 else arr
@@ -540,6 +544,8 @@ class HipImg2ImgPipeline:
             return types.SimpleNamespace(images=[Image.fromarray(a) for a in arr])
         job = self.prepare(prompt, negative_prompt, image, control_image, strength, num_inference_steps,
                            guidance_scale, controlnet_conditioning_scale, generator)
+        if pre_run is not None:
+            pre_run()
         out_u8 = self.run_device_graphed(job, slot) if self.use_graph else self._run_eager(job)
         if output_type == "latent":
             res = job["_result"]

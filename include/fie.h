@@ -464,6 +464,12 @@ int fie_canny_rgb_u8(const uint8_t* rgb, int H, int W, int low, int high, uint8_
 int64_t fie_canny_workspace_bytes(int H, int W);
 int fie_canny_rgb_device_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int low, int high, void* workspace,
                             uint8_t* edges_rgb, int* iterations);
+/* The same in two halves, so that the host can prepare the rest of an edit (tokenise, draw the noise, upload) while the device works: begin launches NMS,
+ * one round of four hysteresis passes, the edge map of that state and an asynchronous copy of the round's four flag words into host_flags (4 ints of PINNED
+ * host memory) and returns without waiting; finish synchronises the stream, runs further rounds only if the round's LAST pass still changed something
+ * (rare: a weak chain that crosses more than three 32x32 tiles), and rewrites the edge map then.  Same result as the one-call form. */
+int fie_canny_rgb_device_begin_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int low, int high, void* workspace, uint8_t* edges_rgb, int* host_flags);
+int fie_canny_rgb_device_finish_u8(fie_ctx* ctx, int H, int W, void* workspace, uint8_t* edges_rgb, int* host_flags, int* iterations);
 
 /* ---- K13 LANCZOS resize on the device, bit-exact with Pillow's 8-bit resample.  Replaces
  * `image.resize((1024, 1024), Image.LANCZOS)` at src/pipeline.py:251 (the PIL image is uploaded at its own size instead).

@@ -104,10 +104,12 @@ class FastEditor:
                                   else "disabled (faster, needs more VRAM)"))
         log("Initialization complete!")
 
-    def _canny_device(self, image, low_threshold, high_threshold, size=None):
+    def _canny_device(self, image, low_threshold, high_threshold, size=None, wait=True):
         """PIL -> (u8 HWC source on the device, u8 HWC edge map on the device): gray, Sobel, NMS and hysteresis run in HIP
         kernels (csrc/canny_device.hip), integer exact.  `size` = (width, height): LANCZOS-resize first, as
-        `image.resize(size, Image.LANCZOS)` does -- on the device for RGB images, through PIL for any other mode."""
+        `image.resize(size, Image.LANCZOS)` does -- on the device for RGB images, through PIL for any other mode.
+        wait=False: returns (source, edge map, finish) with the kernels still in flight; finish() must be called (on the same
+        stream) before the edge map is read -- it waits, and runs the rare extra hysteresis rounds."""
         if size is not None and image.size != tuple(size) and image.mode != "RGB":
             image = image.resize(size, Image.LANCZOS)
         arr = np.array(image)
@@ -116,7 +118,14 @@ class FastEditor:
         src = torch.from_numpy(np.ascontiguousarray(arr[..., :3])).to(self.pipe.ctx.device)
         if size is not None and (src.shape[1], src.shape[0]) != tuple(size):
             src = self.pipe.ctx.resize_lanczos(src, size[1], size[0])
-        return src, self.pipe.ctx.canny_device(src, low_threshold, high_threshold)
+        ctx = self.pipe.ctx
+        if not wait:
+            edges, state = ctx.canny_begin(src, low_threshold, high_threshold)
+            def finish():
+                with self.pipe.eager_lock:                 # the context's stream binding is shared by the threads of in-flight edits
+                    ctx.canny_finish(state)
+            return src, edges, finish
+        return src, ctx.canny_device(src, low_threshold, high_threshold)
 
     def preprocess_image(self, image, low_threshold=100, high_threshold=200):
         """PIL RGB -> 3-channel PIL Canny edge map (reference :183-210)."""
@@ -132,12 +141,14 @@ class FastEditor:
         # on the device (bit-exact with Pillow, csrc/resize.hip) on the uploaded original, and preprocess_image()'s PIL round
         # trip (D2H of the edge map + H2D again inside the pipeline) is skipped
         slot = getattr(self._tls, "slot", 0)
+        # the Canny kernels are launched and NOT waited for: the pipeline's host-side preparation (tokeniser, noise draws, uploads) runs
+        # meanwhile and calls finish (the flag read-back of the hysteresis fixed point) right before it issues the device job
         with self.pipe.eager_lock, torch.cuda.stream(self.pipe.slot_stream(slot)):
-            source_dev, control_dev = self._canny_device(image, canny_low_threshold, canny_high_threshold, size=(1024, 1024))
+            source_dev, control_dev, finish = self._canny_device(image, canny_low_threshold, canny_high_threshold, size=(1024, 1024), wait=False)
         return self.pipe(slot=slot, prompt=prompt, negative_prompt=negative_prompt, image=source_dev,
                          control_image=control_dev, strength=strength, num_inference_steps=num_inference_steps,
                          guidance_scale=guidance_scale, controlnet_conditioning_scale=controlnet_conditioning_scale,
-                         generator=generator).images[0]
+                         generator=generator, pre_run=finish).images[0]
 
     def edit_batch(self, images, prompts, negative_prompts=None, strength=0.80, num_inference_steps=4, guidance_scale=1.5,
                    controlnet_conditioning_scale=0.5, canny_low_threshold=100, canny_high_threshold=200, seed=None):
