@@ -556,7 +556,7 @@ def main():
             "metric": "PIE-Bench images/sec @1024^2 SSD-1B fp16 4-step", "value": round(value, 4), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.weights == "f16" else ("e4m3 x e4m3 on the block-scaled MFMA (fp32 accumulate) for the transformer-block projections of the UNet / ControlNet: "
-                                                                           "e4m3 weights with per-channel scales, e4m3 activations written by LayerNorm / attention / GEGLU at unit scale (saturating); "
+                                                                           "e4m3 weights with per-channel scales, e4m3 activations written by LayerNorm / attention / GEGLU / GroupNorm at calibrated power-of-two scales (saturating, NaN kept); "
                                                                            "e4m3 weights x f16 activations for their other GEMMs / convs; f16 elsewhere"),
             "data": "synthetic (seeded PIE-Bench-shaped 512^2 images, real PIE-Bench prompts, seeded random-init weights, stand-in tokenizer)",
             "timed_region": "K serial FastEditor.edit() calls on K different items, PIL in -> PIL out, timer placed as run_batch.py:208-221 "

@@ -28,11 +28,13 @@ class HipImg2ImgPipeline:
         """cfgs / sds: dicts with keys unet, controlnet, vae, clip_l, clip_g (configs / diffusers-named state dicts).
         weight_dtype "f8e4m3" (BASELINE config 5): the Linear / conv weights of the UNet and the ControlNet are stored as fp8 e4m3
         with per-output-channel scales (csrc/gemm_w8.hip); the 1280-wide 3x3 convs, VAE, text encoders, embedding MLPs and the few convs
-        the LDS-DMA kernels cannot address (Cin % 64 != 0) stay fp16.  ACTIVATIONS: the transformer-block projections read e4m3 written by
-        LayerNorm / attention / the GEGLU epilogue at unit scale (saturating at +-448) and run the block-scaled fp8 MFMA
-        (csrc/gemm_x8.hip); every other fp8-weight GEMM / conv rounds its fp16 activations to e4m3 per fragment in registers.  So this
-        configuration is W8A8 at a fixed activation scale of 1 (not "fp8 weights only"): parity is pinned on seeded random weights
-        (SSIM vs the fp16 pipeline, tests/test_fp8_gpu.py); on real checkpoints activations beyond +-448 would clip."""
+        the LDS-DMA kernels cannot address (Cin % 64 != 0) stay fp16.  ACTIVATIONS: the transformer-block projections and the resnet convs read e4m3
+        written by LayerNorm / attention / the GEGLU epilogue / GroupNorm (value / s, saturating at +-448, NaN kept) and run the block-scaled fp8
+        MFMA (csrc/gemm_x8.hip) with s folded into the weight scale; every other fp8-weight GEMM / conv rounds its fp16 activations to e4m3 per
+        fragment in registers.  So this configuration is W8A8 (not "fp8 weights only").  The per-tensor scales s are 1 until calibrate_fp8() has
+        measured them on one edit (powers of two; load_fp8_scales() takes a stored set): on real checkpoints, activations beyond +-448 clip
+        without that step.  Parity: SSIM vs the fp16 pipeline and an evaluation against the oracle on the dequantised weights
+        (tests/test_fp8_gpu.py, tests/test_sdxl_gpu.py)."""
         if weight_dtype not in ("f16", "f8e4m3"):
             raise ValueError(f"weight_dtype {weight_dtype!r}: 'f16' or 'f8e4m3'")
         if weight_dtype != "f16" and ctx.f32:
@@ -343,9 +345,15 @@ class HipImg2ImgPipeline:
             l.amax = None
             l.s8 = [2.0 ** math.ceil(math.log2(a * margin / 448.0)) if a > 0 else 1.0 for a in am]
             scales[name] = list(l.s8)
-        self._graphs.clear()
-        self._n_forked = 0
+        self._drop_graphs()
         return scales
+
+    def _drop_graphs(self):
+        """Captured graphs hold the scales (and kernels) of their capture: forget them AND their memory pools (a pool whose graphs are all gone cannot
+        take a new capture: torch's allocator asserts on its use count)."""
+        self._graphs.clear()
+        self._pools.clear()
+        self._n_forked = 0
 
     def load_fp8_scales(self, scales):
         """Scales from an earlier calibrate_fp8 of the same model (a JSON-able dict); unknown / missing layer names raise."""
@@ -356,8 +364,7 @@ class HipImg2ImgPipeline:
             if len(sc) != len(layers[name].s8) or any(not (v > 0) for v in sc):
                 raise ValueError(f"load_fp8_scales: bad scales for {name}")
             layers[name].s8 = [float(v) for v in sc]
-        self._graphs.clear()
-        self._n_forked = 0
+        self._drop_graphs()
 
     def _tune_mode(self):
         """fie_gemm_autotune mode of a pass that may meet new shapes: 1 (time them), or 2 (remembered choices only) when the context's choices

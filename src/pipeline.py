@@ -171,6 +171,18 @@ class FastEditor:
                          strength=strength, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
                          controlnet_conditioning_scale=controlnet_conditioning_scale, generator=gens).images
 
+    def calibrate_fp8(self, image, prompt, negative_prompt="", strength=0.80, num_inference_steps=4, guidance_scale=1.5,
+                      controlnet_conditioning_scale=0.5, canny_low_threshold=100, canny_high_threshold=200, seed=0, margin=2.0):
+        """[additive] FastEditor(weight_dtype="f8e4m3") only: measure the activation scales of the fp8 configuration on ONE representative edit
+        (same arguments as edit(); fie_amd/pipe.py: calibrate_fp8 -- per-tensor max |x| -> power-of-two scale with `margin` head-room).  Without it the
+        scales are 1 and activations beyond +-448 clip.  Returns the {layer: scales} dict; `self.pipe.load_fp8_scales(d)` restores a stored one."""
+        with self.pipe.eager_lock:
+            src, ctl = self._canny_device(image, canny_low_threshold, canny_high_threshold, size=(1024, 1024))
+        return self.pipe.calibrate_fp8(prompt=prompt, image=src, control_image=ctl, margin=margin, negative_prompt=negative_prompt, strength=strength,
+                                       num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                                       controlnet_conditioning_scale=controlnet_conditioning_scale,
+                                       generator=torch.Generator(device=self.device).manual_seed(seed))
+
     def set_in_flight(self, n):
         """[additive] allow `n` edits in flight on this GPU: edit() may then be called from up to n worker threads (see
         `worker_slot`); each thread replays its own hipGraph slot on its own stream.  Measured on MI355X: 2 in flight =

@@ -143,6 +143,34 @@ def test_fp8_pipeline_against_fp16_pipeline(fie):
         HipImg2ImgPipeline(fie, cfgs, sds, weight_dtype="int4")
 
 
+def test_fasteditor_fp8_calibration_roundtrip():
+    """The public entry of the calibration (src/pipeline.py: FastEditor.calibrate_fp8, additive): scales are powers of two, the calibrated editor still
+    edits (close to its uncalibrated self: nothing clips on these weights either way), captured graphs are dropped and re-captured with the new scales,
+    and a stored dict loads back."""
+    import math
+    from PIL import Image
+    from src.pipeline import FastEditor
+    ed = FastEditor(model_name="tiny", enable_cpu_offload=False, use_full_controlnet=True, weight_dtype="f8e4m3")
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, 255, (96, 128, 3), dtype=np.uint8)
+    a[20:70, 30:100] = 200
+    img = Image.fromarray(a)
+    before = np.asarray(ed.edit(img, "a [blue] square", strength=0.8, seed=3))
+    assert len(ed.pipe._graphs) >= 1
+    scales = ed.calibrate_fp8(img, "a [blue] square", strength=0.8)
+    assert ed.pipe._graphs == {} and len(scales) > 4
+    flat = [v for sc in scales.values() for v in sc]
+    assert all(v > 0 and math.log2(v) == round(math.log2(v)) for v in flat) and any(v != 1.0 for v in flat)
+    after = np.asarray(ed.edit(img, "a [blue] square", strength=0.8, seed=3))
+    d = np.abs(after.astype(int) - before.astype(int))
+    print(f"tiny fp8 editor, calibrated vs unit scales: mean |du8| {d.mean():.2f}, max {d.max()}; {len(flat)} tensors, scales 2^{math.log2(min(flat)):.0f}..2^{math.log2(max(flat)):.0f}")
+    assert after.std() > 5 and d.mean() < 8.0
+    ed.pipe.load_fp8_scales(scales)
+    assert np.array_equal(np.asarray(ed.edit(img, "a [blue] square", strength=0.8, seed=3)), after)
+    with pytest.raises(ValueError, match="f8e4m3"):
+        FastEditor(model_name="tiny", enable_cpu_offload=False).calibrate_fp8(img, "x")
+
+
 @pytest.mark.parametrize("code", [0, 42, 43, 47, 51, 52, 54, 62, 63, 30062, 20051, 20054])
 def test_gemm_x8_fp8_activations_matches_quantised_reference(fie8, code):
     """fie_gemm_x8_f16 (csrc/gemm_x8.hip): e4m3 activations x e4m3 weights on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales.
