@@ -147,17 +147,20 @@ static void canny_out(fie_ctx* ctx, const uint8_t* map, int H, int W, uint8_t* e
     fie_launch(ctx, canny_out_kernel, dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, map, n, edges_rgb);
 }
 
-// Asynchronous first half: NMS, one round of hysteresis, the edge map of that state, and the round's flags on their way to `host_flags` (kPasses ints
-// of PINNED host memory).  Nothing is waited for: the host goes on with its own preparation while the device works.
-int fie_canny_rgb_device_begin_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int low, int high, void* workspace, uint8_t* edges_rgb, int* host_flags) {
-    FIE_REQUIRE(ctx && rgb && workspace && edges_rgb && host_flags && H > 0 && W > 0, "fie_canny_rgb_device_begin_u8: bad argument");
+// Asynchronous first half: NMS, `rounds` rounds of hysteresis, the edge map of that state, and the LAST round's flags on their way to `host_flags`
+// (kPasses ints of PINNED host memory).  Nothing is waited for: the host goes on with its own work while the device does this.
+int fie_canny_rgb_device_begin_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int low, int high, int rounds, void* workspace, uint8_t* edges_rgb,
+                                  int* host_flags) {
+    FIE_REQUIRE(ctx && rgb && workspace && edges_rgb && host_flags && H > 0 && W > 0 && rounds >= 1 && rounds <= 64, "fie_canny_rgb_device_begin_u8: bad argument");
     if (low > high) { int t = low; low = high; high = t; }
     uint8_t* map = (uint8_t*)workspace;
     int* flags = (int*)(map + (((size_t)H * W + 63) / 64) * 64);
     fie_launch(ctx, canny_nms_kernel, dim3((W + TX - 1) / TX, (H + TY - 1) / TY), dim3(TX, TY), 0, rgb, H, W, low, high, map);
     FIE_LAUNCH_CHECK();
-    const int rc = canny_round(ctx, map, H, W, flags);
-    if (rc != FIE_OK) return rc;
+    for (int r = 0; r < rounds; ++r) {
+        const int rc = canny_round(ctx, map, H, W, flags);
+        if (rc != FIE_OK) return rc;
+    }
     canny_out(ctx, map, H, W, edges_rgb);
     FIE_LAUNCH_CHECK();
     if (hipMemcpyAsync(host_flags, flags, kPasses * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
@@ -168,13 +171,13 @@ int fie_canny_rgb_device_begin_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W
 }
 
 // Second half: waits for the first (SYNCHRONISES the ctx stream); when its last pass still changed something, further rounds until one ends unchanged, and
-// the edge map again.  iterations (optional): hysteresis passes launched in all.
+// the edge map again.  iterations (optional): hysteresis passes launched HERE (0: begin's rounds had reached the fixed point, edges_rgb was final).
 int fie_canny_rgb_device_finish_u8(fie_ctx* ctx, int H, int W, void* workspace, uint8_t* edges_rgb, int* host_flags, int* iterations) {
     FIE_REQUIRE(ctx && workspace && edges_rgb && host_flags && H > 0 && W > 0, "fie_canny_rgb_device_finish_u8: bad argument");
     uint8_t* map = (uint8_t*)workspace;
     int* flags = (int*)(map + (((size_t)H * W + 63) / 64) * 64);
     const int max_iters = ((W + HT - 1) / HT) * ((H + HT - 1) / HT) + 2 * kPasses;       // a strong seed can cross every tile at most once
-    int iters = kPasses;
+    int iters = 0;
     bool more = false;
     for (;;) {
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { fie_set_error("fie_canny_rgb_device_finish_u8: synchronisation failed"); return FIE_EHIP; }
@@ -201,9 +204,12 @@ int fie_canny_rgb_device_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int 
                             uint8_t* edges_rgb, int* iterations) {
     FIE_REQUIRE(ctx && rgb && workspace && edges_rgb && H > 0 && W > 0, "fie_canny_rgb_device_u8: bad argument");
     int host_flags[kPasses] = {0, 0, 0, 0};               // pageable: the copy is then synchronous with respect to the host, which this entry is anyway
-    const int rc = fie_canny_rgb_device_begin_u8(ctx, rgb, H, W, low, high, workspace, edges_rgb, host_flags);
+    int rc = fie_canny_rgb_device_begin_u8(ctx, rgb, H, W, low, high, 1, workspace, edges_rgb, host_flags);
     if (rc != FIE_OK) return rc;
-    return fie_canny_rgb_device_finish_u8(ctx, H, W, workspace, edges_rgb, host_flags, iterations);
+    int more = 0;
+    rc = fie_canny_rgb_device_finish_u8(ctx, H, W, workspace, edges_rgb, host_flags, &more);
+    if (iterations) *iterations = kPasses + more;
+    return rc;
 }
 
 }  // extern "C"

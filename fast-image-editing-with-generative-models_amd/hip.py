@@ -62,7 +62,7 @@ SIGNATURES = {
     "fie_attention_f16_o8": [_P, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I, _F],
     "fie_quantize_f8": [_P, _P, _L, _P, _L, _L, _I, _F],
     "fie_amax_f16": [_P, _P, _L, _L, _I, _P],
-    "fie_canny_rgb_device_begin_u8": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "fie_canny_rgb_device_begin_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "fie_canny_rgb_device_finish_u8": [_P, _I, _I, _P, _P, _P, _P],
     "fie_weights_clear_prefix": [_P, _c.c_char_p],
     "fie_step_cache_bind": [_P, _c.c_char_p, _P, _L],
@@ -823,9 +823,9 @@ class Context:
         self.canny_passes = it.value
         return out
 
-    def canny_begin(self, rgb_u8, low=100, high=200):
-        """First half of canny_device() (include/fie.h: fie_canny_rgb_device_begin_u8): launches everything and returns (edge map tensor, state) without
-        waiting; the tensor's contents are final once canny_finish(state) has returned."""
+    def canny_begin(self, rgb_u8, low=100, high=200, rounds=1):
+        """First half of canny_device() (include/fie.h: fie_canny_rgb_device_begin_u8): launches NMS + `rounds` rounds of four hysteresis passes + the
+        edge map and returns (edge map tensor, state) without waiting; canny_finish(state) waits and tells whether that map was final."""
         self.sync_stream()
         h, w, _ = rgb_u8.shape
         assert rgb_u8.is_contiguous() and rgb_u8.dtype == torch.uint8
@@ -835,15 +835,18 @@ class Context:
         flags = cache.get(self._stream)
         if flags is None:
             flags = cache[self._stream] = torch.zeros(4, dtype=torch.int32).pin_memory()
-        _chk(lib().fie_canny_rgb_device_begin_u8(self.h, _p(rgb_u8), h, w, int(low), int(high), _p(ws), _p(out), flags.data_ptr()))
-        return out, (h, w, ws, out, flags, rgb_u8)
+        _chk(lib().fie_canny_rgb_device_begin_u8(self.h, _p(rgb_u8), h, w, int(low), int(high), int(rounds), _p(ws), _p(out), flags.data_ptr()))
+        return out, (h, w, ws, out, flags, rgb_u8, int(rounds))
 
     def canny_finish(self, state):
-        h, w, ws, out, flags, _src = state
+        """Waits for canny_begin's work; runs the further hysteresis rounds if its last pass had still changed something (the edge map tensor is then
+        rewritten).  Returns the tensor; `self.canny_more` = passes launched here (0: the map was final when begin's kernels ended)."""
+        h, w, ws, out, flags, _src, rounds = state
         self.sync_stream()
         it = _I(0)
         _chk(lib().fie_canny_rgb_device_finish_u8(self.h, h, w, _p(ws), _p(out), flags.data_ptr(), ctypes.byref(it)))
-        self.canny_passes = it.value
+        self.canny_more = it.value
+        self.canny_passes = 4 * rounds + it.value
         return out
 
     def latent_prep(self, moments, eps_post, noise, hw, sf, sqrt_ab, sqrt_1mab, latents, model_in):

@@ -464,11 +464,14 @@ int fie_canny_rgb_u8(const uint8_t* rgb, int H, int W, int low, int high, uint8_
 int64_t fie_canny_workspace_bytes(int H, int W);
 int fie_canny_rgb_device_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int low, int high, void* workspace,
                             uint8_t* edges_rgb, int* iterations);
-/* The same in two halves, so that the host can prepare the rest of an edit (tokenise, draw the noise, upload) while the device works: begin launches NMS,
- * one round of four hysteresis passes, the edge map of that state and an asynchronous copy of the round's four flag words into host_flags (4 ints of PINNED
- * host memory) and returns without waiting; finish synchronises the stream, runs further rounds only if the round's LAST pass still changed something
- * (rare: a weak chain that crosses more than three 32x32 tiles), and rewrites the edge map then.  Same result as the one-call form. */
-int fie_canny_rgb_device_begin_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int low, int high, void* workspace, uint8_t* edges_rgb, int* host_flags);
+/* The same in two halves, so that the host need not wait for the hysteresis flag before it goes on: begin launches NMS, `rounds` rounds of four
+ * hysteresis passes, the edge map of that state and an asynchronous copy of the LAST round's four flag words into host_flags (4 ints of PINNED host
+ * memory) and returns without waiting; finish synchronises the stream, runs further rounds only if that round's last pass still changed something
+ * (a weak chain that crosses more than 4 * rounds - 1 tiles of 32x32), rewrites the edge map then, and reports the passes IT launched (0: the map begin
+ * wrote was final).  fie_amd's FastEditor.edit() begins with 4 rounds, issues the whole edit behind it and calls finish at the edit's own final
+ * synchronisation: no host wait at all in the common case, a repeated device job in the rare one.  Same result as the one-call form. */
+int fie_canny_rgb_device_begin_u8(fie_ctx* ctx, const uint8_t* rgb, int H, int W, int low, int high, int rounds, void* workspace, uint8_t* edges_rgb,
+                                  int* host_flags);
 int fie_canny_rgb_device_finish_u8(fie_ctx* ctx, int H, int W, void* workspace, uint8_t* edges_rgb, int* host_flags, int* iterations);
 
 /* ---- K13 LANCZOS resize on the device, bit-exact with Pillow's 8-bit resample.  Replaces

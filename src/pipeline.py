@@ -104,12 +104,15 @@ class FastEditor:
                                   else "disabled (faster, needs more VRAM)"))
         log("Initialization complete!")
 
+    CANNY_ROUNDS = 4            # hysteresis rounds (of four passes) edit() launches without looking at the flags: weak chains across <= 15 tiles of 32x32
+
     def _canny_device(self, image, low_threshold, high_threshold, size=None, wait=True):
         """PIL -> (u8 HWC source on the device, u8 HWC edge map on the device): gray, Sobel, NMS and hysteresis run in HIP
         kernels (csrc/canny_device.hip), integer exact.  `size` = (width, height): LANCZOS-resize first, as
         `image.resize(size, Image.LANCZOS)` does -- on the device for RGB images, through PIL for any other mode.
-        wait=False: returns (source, edge map, finish) with the kernels still in flight; finish() must be called (on the same
-        stream) before the edge map is read -- it waits, and runs the rare extra hysteresis rounds."""
+        wait=False: returns (source, edge map, finish) with the kernels still in flight (NMS + CANNY_ROUNDS hysteresis rounds); finish()
+        -- called once the stream has drained -- returns True when those rounds had NOT reached the fixed point: it has then run the
+        remaining ones and rewritten the edge map, and whatever was computed from the map must be computed again."""
         if size is not None and image.size != tuple(size) and image.mode != "RGB":
             image = image.resize(size, Image.LANCZOS)
         arr = np.array(image)
@@ -120,10 +123,12 @@ class FastEditor:
             src = self.pipe.ctx.resize_lanczos(src, size[1], size[0])
         ctx = self.pipe.ctx
         if not wait:
-            edges, state = ctx.canny_begin(src, low_threshold, high_threshold)
+            edges, state = ctx.canny_begin(src, low_threshold, high_threshold, rounds=self.CANNY_ROUNDS)
+
             def finish():
                 with self.pipe.eager_lock:                 # the context's stream binding is shared by the threads of in-flight edits
                     ctx.canny_finish(state)
+                    return ctx.canny_more > 0
             return src, edges, finish
         return src, ctx.canny_device(src, low_threshold, high_threshold)
 
@@ -141,14 +146,16 @@ class FastEditor:
         # on the device (bit-exact with Pillow, csrc/resize.hip) on the uploaded original, and preprocess_image()'s PIL round
         # trip (D2H of the edge map + H2D again inside the pipeline) is skipped
         slot = getattr(self._tls, "slot", 0)
-        # the Canny kernels are launched and NOT waited for: the pipeline's host-side preparation (tokeniser, noise draws, uploads) runs
-        # meanwhile and calls finish (the flag read-back of the hysteresis fixed point) right before it issues the device job
+        # the Canny kernels (NMS + a fixed number of hysteresis rounds) are launched and NOT waited for: the whole edit is issued behind them on
+        # the same stream, and whether the rounds had reached the fixed point is read when the result is on the host (the flags travelled
+        # with it).  Common case: no host wait in front of the edit.  Rare case (a weak chain across more than 15 tiles): the remaining rounds
+        # run and the device job is repeated on the final edge map -- same result as preprocess_image() + the pipeline call, always
         with self.pipe.eager_lock, torch.cuda.stream(self.pipe.slot_stream(slot)):
             source_dev, control_dev, finish = self._canny_device(image, canny_low_threshold, canny_high_threshold, size=(1024, 1024), wait=False)
         return self.pipe(slot=slot, prompt=prompt, negative_prompt=negative_prompt, image=source_dev,
                          control_image=control_dev, strength=strength, num_inference_steps=num_inference_steps,
                          guidance_scale=guidance_scale, controlnet_conditioning_scale=controlnet_conditioning_scale,
-                         generator=generator, pre_run=finish).images[0]
+                         generator=generator, post_check=finish).images[0]
 
     def edit_batch(self, images, prompts, negative_prompts=None, strength=0.80, num_inference_steps=4, guidance_scale=1.5,
                    controlnet_conditioning_scale=0.5, canny_low_threshold=100, canny_high_threshold=200, seed=None):

@@ -461,8 +461,8 @@ def test_canny_device_bit_exact(fie, seed, h, w, lo, hi):
     assert fie.canny_passes >= 2
     # the two-call form FastEditor.edit() uses (fie_canny_rgb_device_begin_u8 / _finish_u8): nothing is waited for in begin, same bits after finish
     src = torch.from_numpy(img).to(DEV)
-    edges, state = fie.canny_begin(src, lo, hi)
-    assert fie.canny_finish(state) is edges and np.array_equal(edges.cpu().numpy(), got)
+    edges, state = fie.canny_begin(src, lo, hi, rounds=4)
+    assert fie.canny_finish(state) is edges and np.array_equal(edges.cpu().numpy(), got) and fie.canny_more == 0 and fie.canny_passes == 16
 
 
 def test_canny_device_long_chain(fie):
@@ -472,8 +472,8 @@ def test_canny_device_long_chain(fie):
     img[32:, :, :] = 130                      # L1 gradient 4*30 = 120: weak everywhere (100 < 120 <= 200)
     img[32:, :8, :] = 200                     # strong seed at the left end
     got = fie.canny_device(torch.from_numpy(img).to(DEV), 100, 200).cpu().numpy()
-    edges, state = fie.canny_begin(torch.from_numpy(img).to(DEV), 100, 200)       # the first round cannot finish this one: finish runs the further rounds
-    assert np.array_equal(fie.canny_finish(state).cpu().numpy(), got) and fie.canny_passes > 8
+    edges, state = fie.canny_begin(torch.from_numpy(img).to(DEV), 100, 200, rounds=4)       # 16 passes cannot finish this one: finish runs the further rounds
+    assert np.array_equal(fie.canny_finish(state).cpu().numpy(), got) and fie.canny_more > 0 and fie.canny_passes > 30
     ref = ocanny.canny_rgb(img, 100, 200)
     assert np.array_equal(got, ref) and ref[:, 900:].max() == 255 and fie.canny_passes > 8
 

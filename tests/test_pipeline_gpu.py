@@ -203,6 +203,32 @@ def test_run_batch_shard_end_to_end(fie, tmp_path, capsys):
     assert "Invalid path" in capsys.readouterr().out
 
 
+def test_edit_with_unfinished_hysteresis_repeats_the_job(fie):
+    """FastEditor.edit() launches the device Canny with a FIXED number of hysteresis rounds and issues the edit behind it without waiting for the flags
+    (src/pipeline.py: edit, CANNY_ROUNDS; include/fie.h: fie_canny_rgb_device_begin_u8).  An image whose weak chain needs more passes than that -- a
+    weak ramp edge across the whole width, seeded by one strong blob -- must still give exactly the result of the waiting path (preprocess_image() +
+    the pipeline call): the flags say so when the result arrives, the remaining rounds run and the device job is repeated on the final edge map."""
+    from PIL import Image
+    from src.pipeline import FastEditor
+    ed = FastEditor(model_name="tiny", enable_cpu_offload=False, use_full_controlnet=True)
+    a = np.full((1024, 1024, 3), 100, np.uint8)
+    a[512:, :, :] = 130                       # L1 gradient 120 along the row: weak everywhere (100 < 120 <= 200)
+    a[512:, :8, :] = 200                      # one strong seed at the left end: the closure crosses 32 tiles
+    img = Image.fromarray(a)
+    kw = dict(strength=0.5, num_inference_steps=4, guidance_scale=1.5, controlnet_conditioning_scale=0.5)
+    got = np.asarray(ed.edit(img, "a [red] line", seed=5, **kw))
+    assert ed.pipe.repeated_jobs == 1 and ed.pipe.ctx.canny_more > 0
+    ctrl = ed.preprocess_image(img)             # the waiting path: every round, then the call on the PIL edge map as the reference does
+    assert np.asarray(ctrl)[500:524, 900:].max() == 255
+    want = np.asarray(ed.pipe(prompt="a [red] line", negative_prompt="", image=img, control_image=ctrl,
+                              generator=torch.Generator("cuda").manual_seed(5), **kw).images[0])
+    assert np.array_equal(got, want)
+    # an ordinary image: no repeat
+    n = ed.pipe.repeated_jobs
+    ed.edit(synth_image(3, 96), "a [toy]", seed=5, **kw)
+    assert ed.pipe.repeated_jobs == n and ed.pipe.ctx.canny_more == 0
+
+
 def test_two_edits_in_flight_match_serial(fie):
     """Worker threads on separate graph slots / streams produce exactly the serial results (--in_flight 2)."""
     from concurrent.futures import ThreadPoolExecutor

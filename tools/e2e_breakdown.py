@@ -39,6 +39,8 @@ def wrap(obj, name, label, sync=False):
 wrap(ed, "_canny_device", "resize+canny(sync)")
 wrap(pipe, "prepare", "prepare")
 wrap(pipe, "run_device_graphed", "graph launch (host)", sync=True)
+wrap(pipe.ctx, "canny_finish", "canny flags (after the edit)")
+wrap(pipe, "_to_host", "D2H")
 
 
 def phase(tag):
