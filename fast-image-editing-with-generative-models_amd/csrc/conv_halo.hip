@@ -266,7 +266,7 @@ constexpr int n2_wait(int var, bool res, int kind, int t) {
 }
 static_assert(n2_tail(true, K_LAST_F, 8) == 0 && n2_tail(true, K_FIRST, 8) == 0 && n2_st(0, K_FIRST, 8) == 0, "tap 8 carries nothing behind its weights");
 
-template <bool RES, bool GN, bool RB, int VAR, bool STAMP, bool SIDE = false>
+template <bool RES, bool GN, bool RB, int VAR, bool STAMP, bool SIDE = false, bool GNA = false>
 __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
     constexpr int FM = 4, FN = 4, WN = 64;
     constexpr bool ST16 = (VAR & 2) != 0, STM = (VAR & 4) != 0, IM = (VAR & 8) != 0;
@@ -435,12 +435,55 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(p.gn_partial, 0, GN && p.gn_partial ? (p.M / (p.OH * p.OW)) * (p.gn_nch ? p.gn_nch : p.gn_rows >> 5) * p.gn_G * 8 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.res), 0, RES && p.res ? (int)(((int64_t)(p.M - 1) * p.ldr + p.N) * 2) : 0, 0x00020000);
 
+    // ---- GNA: GroupNorm (+ SiLU) of the conv's INPUT applied on the resident halo (upstream resnet.py: norm -> nonlinearity -> conv; the separate
+    // apply kernel -- one read and one write of the whole tensor -- disappears).  Every lane normalises, in place, the 16 bytes it DMA'd itself (its own
+    // vmcnt says when they have landed), two taps after issuing them, 8 bytes behind each of two MFMA groups: y = silu(x * sc[c] + sh[c]) with the
+    // per-(image, channel) coefficients of fie_groupnorm_coef_f16 (the same fp32 expression as gn_apply_kernel: same bits), from a table in LDS
+    // behind the dump; pixels outside the image stay the zeros the range check loaded (the conv pads the NORMALISED tensor with zeros).
+    auto gna_half = [&](auto slc, auto halfc, int buf, int chunk_c, int yy, int xx) {
+        constexpr int SL = decltype(slc)::value, HALF = decltype(halfc)::value;
+        unsigned t = hq[SL];
+        asm volatile("" : "+v"(t));
+        const int hy = (int)(t >> 8), hx = (int)(t & 255u);
+        const int iy = yy + hy - 1, ix = xx + hx - 1;
+        const bool okp = hy < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const unsigned chunk8 = (unsigned)((lane & 7) ^ (hx & 7));
+        char* const dst = reinterpret_cast<char*>(halo_dst(SL, buf)) + lane * 16 + HALF * 8;
+        const float4* tab = reinterpret_cast<const float4*>(lds + kLdsHalo + ((unsigned)chunk_c * 64u + chunk8 * 8u + HALF * 4u) * 8u);
+        const u32x2 xv = *reinterpret_cast<const u32x2*>(dst);
+        const float4 c0 = tab[0], c1 = tab[1];
+        f16x4 xh;
+        __builtin_memcpy(&xh, &xv, 8);
+        float y0f = (float)xh[0] * c0.x + c0.y, y1f = (float)xh[1] * c0.z + c0.w, y2f = (float)xh[2] * c1.x + c1.y, y3f = (float)xh[3] * c1.z + c1.w;
+        if (p.gna_silu) { y0f = fie_silu(y0f); y1f = fie_silu(y1f); y2f = fie_silu(y2f); y3f = fie_silu(y3f); }
+        const f16x4 yh = {(half_t)y0f, (half_t)y1f, (half_t)y2f, (half_t)y3f};
+        u32x2 yv;
+        __builtin_memcpy(&yv, &yh, 8);
+        if (!okp) yv = (u32x2){0u, 0u};
+        *reinterpret_cast<u32x2*>(dst) = yv;
+    };
+    if constexpr (GNA) {                                       // the coefficient table of this block's image (launcher: one image per launch): Cin x (sc, sh) floats
+        float* const tab = reinterpret_cast<float*>(lds + kLdsHalo);
+        for (int i = tid; i < 2 * p.Cin; i += 512) tab[i] = p.gna_tab[i];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // before any LDS-DMA is in flight: the counted waits below count DMA pieces only
+    }
+
     // ---- prologue: the first tile's first halo, the weights of its K-steps 0 and 1
 #pragma unroll
     for (int i = 0; i < HSLOTS; ++i) bload16(rs_a, halo_dst(i, 0), halo_off(i, img, y0, x0), 0u);
     issue_w(0, 0u);
     issue_w(1, cin2);
-    wait_vm_barrier<RWH>();
+    if constexpr (GNA) {                                       // the first halo is normalised here, in the open (every later one under MFMAs)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RWH) : "memory");
+        __builtin_amdgcn_s_barrier();                          // the table: every thread's part written (lgkmcnt(0) above) before anybody reads it
+        static_for([&](auto ic) {
+            gna_half(ic, std::integral_constant<int, 0>{}, 0, 0, y0, x0);
+            gna_half(ic, std::integral_constant<int, 1>{}, 0, 0, y0, x0);
+        }, std::make_integer_sequence<int, HSLOTS>{});
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        wait_vm_barrier<RWH>();
+    }
     if (grp == 1) __builtin_amdgcn_s_barrier();
     stamp(5);
 
@@ -593,6 +636,13 @@ __global__ __launch_bounds__(512) void conv_halo2_kernel(GemmArgs p) {
                 for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[kh][i], fa[kh][j], acc[i][j], 0, 0, 0);
             }
             if constexpr (RLT) { __builtin_amdgcn_sched_barrier(0); resload1(2 * Gs); resload1(2 * Gs + 1); __builtin_amdgcn_sched_barrier(0); }
+            // GNA: half a halo piece (8 bytes of the 16 this lane DMA'd two taps ago) is normalised in place behind MFMA groups 2 and 5
+            if constexpr (GNA && T >= 2 && T < 8 && KIND != K_LAST_N && KIND != K_LASTREG_S && (Gs == 2 || Gs == 5)) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (KIND == K_LAST_F) gna_half(std::integral_constant<int, T - 2>{}, std::integral_constant<int, Gs == 2 ? 0 : 1>{}, hpf_buf, 0, y0n, x0n);
+                else gna_half(std::integral_constant<int, T - 2>{}, std::integral_constant<int, Gs == 2 ? 0 : 1>{}, hpf_buf, c + 1, y0, x0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (IM) { __builtin_amdgcn_sched_barrier(0); slot(gc); __builtin_amdgcn_sched_barrier(0); }
             else if constexpr (STM && (Gs == 3 || Gs == 4)) { __builtin_amdgcn_sched_barrier(0); slot(gc); __builtin_amdgcn_sched_barrier(0); }
         };
@@ -922,6 +972,8 @@ int fie_conv_halo_init(void) {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo2_kernel<false, false, false, 6, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo2_kernel<false, true, false, 6, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo);
     if (e == hipSuccess) e = halo2_attr<true, true, false, 6, true>();
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo2_kernel<false, true, false, 6, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo + 8192);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo2_kernel<true, true, false, 6, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsHalo + 8192);
     if (e != hipSuccess) {
         fie_set_error("conv_halo: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return FIE_EHIP;
@@ -941,6 +993,15 @@ bool fie_conv_halo_ok(const GemmArgs& a) {
            !a.res && !a.rowbias && a.act == FIE_ACT_NONE && a.scale == 1.f && a.lda2 * 2 * (int64_t)a.OW * a.OH < (1ll << 31) && a.lda3 * 2 * (int64_t)a.OW * a.OH < (1ll << 31);
 }
 
+// GNA (the input's GroupNorm + SiLU applied on the resident halo): the persistent form, ONE image, GroupNorm sums armed for the output (every resnet conv
+// of the VAE has them), no row bias, no side inputs, Cin <= 1024 (an 8 KiB coefficient table behind the dump), as many column tiles as fit the grid
+bool fie_conv_halo_gna_ok(const GemmArgs& a) {
+    if (!fie_conv_halo_ok(a) || a.A2 || a.rowbias) return false;
+    const int nbn = (a.N + BNH - 1) / BNH;
+    return a.M == a.OH * a.OW && a.Cin >= 2 * BK && a.Cin <= 1024 && a.N % BNH == 0 && nbn <= 64 && a.act == FIE_ACT_NONE && a.scale == 1.f && a.gn_partial != nullptr &&
+           (a.gn_cg == 4 || a.gn_cg == 8 || a.gn_cg == 16);
+}
+
 // variant: 0 = v1 (one tile per block, code 71), 1 = v1 with stamps (73), 2 = v2: persistent blocks, deferred 16-byte stores issued inside the MFMA
 // segments (72; with at most one tile per block it runs as v1: nothing to defer into), 4 = v2 with stamps (74), 5 = v2 with 8-byte stores issued in
 // the load segments (76: the first form, kept for A/B).  Measured and not kept (profiles/r04_halo_conv.md): the stores counted in the waits
@@ -954,6 +1015,16 @@ int fie_launch_conv_halo(fie_ctx* ctx, GemmArgs& a, int variant) {
     const int tiles = a.nbm * a.nbn;
     const bool side = a.A2 != nullptr;
     FIE_REQUIRE(!(side && variant != 2), "halo-resident conv: 1x1 side inputs run on tile code 72 only");
+    if (a.gna_tab) {                                           // GroupNorm of the input applied on the resident halo: the persistent form with GroupNorm sums out, one image
+        FIE_REQUIRE(fie_conv_halo_gna_ok(a), "halo-resident conv with the input's GroupNorm applied in LDS: shape or epilogue not built (fie_conv3x3_gn_ok)");
+        int g = tiles < ctx->num_cus ? tiles : ctx->num_cus;
+        g -= g % a.nbn;
+        const int lds_bytes = kLdsHalo + a.Cin * 8;
+        if (a.res) fie_launch(ctx, (conv_halo2_kernel<true, true, false, 6, false, false, true>), dim3((unsigned)g), dim3(512), lds_bytes, a);
+        else fie_launch(ctx, (conv_halo2_kernel<false, true, false, 6, false, false, true>), dim3((unsigned)g), dim3(512), lds_bytes, a);
+        FIE_LAUNCH_CHECK();
+        return FIE_OK;
+    }
     if (!side && variant >= 2 && tiles <= ctx->num_cus) variant = variant == 4 ? 1 : 0;      // one tile per block: the one-tile form (its epilogue is shorter than a tile end + a flush)
     // v2 stores during the first chunk and loads residuals in the last: two chunks at least; whole 128-channel column tiles (a wave whose channels lie
     // past N would issue stores / loads that the range check drops whole, and those do not keep the vmcnt order the counted waits rely on); row bias and

@@ -55,6 +55,7 @@ struct GemmArgs {
     // (16 pixels of one patch row) then starts frag_ld = OW rows after fragment j - 1 instead of 16: the epilogue's row of fragment (wm, j), lane fr
     // is m0 + (wm * FM + j) * frag_ld + fr with m0 = the patch's first pixel.  0 = the ordinary consecutive-row tile (16).
     int frag_ld;
+    const float* gna_tab; int gna_silu;        // conv_halo.hip, GNA: per-(image, channel) GroupNorm coefficients (sc, sh) of the conv's INPUT (fie_groupnorm_coef_f16), applied on the resident halo
 };
 
 // oscat == 2: the block's parity comes from its (remapped) tile id; the four parity tiles of one output tile are neighbours in time and
@@ -560,6 +561,7 @@ int fie_gemm_init(void);           // same for the kernels of gemm_conv.hip
 // conv_halo.hip: the halo-resident 3x3 conv (tile code 71; 73 = with cycle stamps): a block = a 16x16 output patch x 128 channels
 int fie_launch_conv_halo(fie_ctx* ctx, fie_gemm::GemmArgs& a, int stamped);
 bool fie_conv_halo_ok(const fie_gemm::GemmArgs& a);
+bool fie_conv_halo_gna_ok(const fie_gemm::GemmArgs& a);
 int fie_conv_halo_init(void);
 // gemm_w8.hip: fp8-weight ring kernels; code 62 = 256x128 (8 waves), 42 = 128x64, 43 = 64x64
 int fie_launch_gemm_w8(fie_ctx* ctx, const fie_gemm::GemmArgs& a, int conv, int code);

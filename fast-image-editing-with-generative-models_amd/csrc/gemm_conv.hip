@@ -863,6 +863,10 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
     const bool dma_ok = a.a1_bytes < (1ll << 31) && a.a2_bytes < (1ll << 31) && a.w_bytes < (1ll << 31) && c_span <= (1ll << 30) && r_span <= (1ll << 30) &&
                         (MODE == 1 ? a.Cin % (a.a_scale != 0.f ? 2 * BK : BK) == 0 : (a.K1 == a.K || a.K1 % BK == 0));
     FIE_REQUIRE(!(MODE == 1 && a.A2 && !dma_ok), "conv + 1x1 side inputs: tensors too large for the LDS-DMA kernels");
+    if (MODE == 1 && a.gna_tab) {                          // the input's GroupNorm applied on the resident halo: one kernel family, no choice to make
+        FIE_REQUIRE(dma_ok && fie_conv_halo_gna_ok(a), "fie_conv3x3_gn_nhwc_f16: shape / epilogue not built for the fused form (ask fie_conv3x3_gn_ok first)");
+        return run_code<MODE>(ctx, a, 72, -1, dma_ok, 1);
+    }
     int code = heuristic_code<MODE>(ctx, a, dma_ok);
     int order = -1;                // 0: n-tiles fastest (an XCD owns a range of activation rows), 1: m-tiles fastest; -1: estimate
     int split = 1;                 // encoded choices: split-K factor * 10000 + (1000 / 2000: forced tile order) + tile code
@@ -1182,7 +1186,8 @@ int fie_gemm_x8_f16(fie_ctx* ctx, const void* A8, int64_t lda, const void* W8pac
 static int conv_impl(const char* who, fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, int upsample2x, int stride, int pad_mode,
                      const void* Wpacked, int64_t ldw, const float* w_scale, void* Y, int64_t ldc, int Cout, const void* bias,
                      const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ldr, float scale, int act,
-                     const void* X2 = nullptr, int64_t ld2 = 0, int C2 = 0, const void* X3 = nullptr, int64_t ld3 = 0, int C3 = 0) {
+                     const void* X2 = nullptr, int64_t ld2 = 0, int C2 = 0, const void* X3 = nullptr, int64_t ld3 = 0, int C3 = 0,
+                     const float* gna_tab = nullptr, int gna_silu = 0) {
     const GnTarget gn = grab_gn_target(ctx);
     FIE_REQUIRE(ctx && X && Wpacked && Y, "%s: NULL ctx/X/W/Y", who);
     FIE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "%s: bad shape", who);
@@ -1216,6 +1221,7 @@ static int conv_impl(const char* who, fie_ctx* ctx, const void* X, int B, int H,
         FIE_REQUIRE(a.a2_bytes < (1ll << 31) && a.a3_bytes < (1ll << 31), "%s: side inputs too large", who);
     }
     a.w_bytes = fie_roundup(Cout, 128) * ldw * (w_scale ? 1 : 2);
+    a.gna_tab = gna_tab; a.gna_silu = gna_silu;
     if (int rc = take_gn_target(who, gn, a)) return rc;
     return launch<1>(ctx, a);
 }
@@ -1249,6 +1255,25 @@ int fie_conv3x3_x8_nhwc_f16(fie_ctx* ctx, const void* X8, int B, int H, int W, i
     a.w_bytes = fie_roundup(Cout, 128) * ldw;
     if (int rc = take_gn_target(who, gn, a)) return rc;
     return launch<1>(ctx, a);
+}
+
+// GroupNorm (+ SiLU) -> conv3x3 in ONE launch: the conv reads the UN-normalised tensor and applies y = silu(x * sc[c] + sh[c]) to every halo chunk while it
+// is resident in LDS (csrc/conv_halo.hip, GNA), with the per-(image, channel) coefficients of fie_groupnorm_coef_f16.  Exists for what
+// fie_conv3x3_gn_ok says: one image, H, W % 16 == 0, 128 <= Cin <= 1024 in whole 64-channel chunks, Cout % 128 == 0, an armed fie_gn_stats_target
+// for the output with 4 / 8 / 16 channels per group, optional bias and residual.
+int fie_conv3x3_gn_ok(fie_ctx* ctx, int B, int H, int W, int Cin, int Cout, int out_groups) {
+    (void)ctx;                                              // a pure function of the shape (the C++ walks ask it in their planning pass, without a context)
+    if (B != 1 || H <= 0 || W <= 0 || H % 16 || W % 16 || Cin % BK || Cin < 2 * BK || Cin > 1024 || Cout % 128 || Cout / 128 > 64 || out_groups <= 0 || Cout % out_groups) return 0;
+    const int cg = Cout / out_groups;
+    if (cg != 4 && cg != 8 && cg != 16) return 0;
+    return (int64_t)H * W * Cin * 2 < (1ll << 31) && (int64_t)H * W * Cout * 2 <= (1ll << 30) ? 1 : 0;
+}
+
+int fie_conv3x3_gn_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, const float* coef, int silu, const void* Wpacked, int64_t ldw, void* Y,
+                            int64_t ldc, int Cout, const void* bias, const void* residual, int64_t ldr) {
+    FIE_REQUIRE(coef != nullptr, "fie_conv3x3_gn_nhwc_f16: NULL coefficient table");
+    return conv_impl("fie_conv3x3_gn_nhwc_f16", ctx, X, B, H, W, Cin, 0, 1, 0, Wpacked, ldw, nullptr, Y, ldc, Cout, bias, nullptr, 0, residual, ldr, 1.0f,
+                     FIE_ACT_NONE, nullptr, 0, 0, nullptr, 0, 0, coef, silu ? 1 : 0);
 }
 
 int fie_conv3x3_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, int upsample2x, int stride,

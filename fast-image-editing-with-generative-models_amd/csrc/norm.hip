@@ -595,7 +595,58 @@ int groupnorm_stats_t(const char* who, fie_ctx* ctx, const void* X, int C, void*
     return FIE_OK;
 }
 
+// GroupNorm as per-(image, channel) coefficients instead of a normalised tensor: coef[b][c] = (sc, sh) with sc = rstd * gamma, sh = beta - mean * sc, the
+// very fp32 values gn_apply_kernel forms per thread -- for a consumer that applies y = x * sc + sh itself (conv_halo.hip, GNA)
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void gn_coef_kernel(GnArgsT<T> p, float* coef) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    const int g = c / p.cg;
+    const float mean = p.stats[(b * p.G + g) * 2], rstd = p.stats[(b * p.G + g) * 2 + 1];
+    const float sc = rstd * (float)p.gamma[c];
+    const float sh = (float)p.beta[c] - mean * sc;
+    reinterpret_cast<float2*>(coef)[(int64_t)b * p.C + c] = make_float2(sc, sh);
+}
+}  // namespace
+
 extern "C" {
+
+int fie_groupnorm_coef_f16(fie_ctx* ctx, int C, int B, int64_t rows_per_image, int groups, const void* gamma, const void* beta, float eps, const void* partial,
+                           void* workspace, int partial_groups, float* coef) {
+    const char* who = "fie_groupnorm_coef_f16";
+    FIE_REQUIRE(ctx && gamma && beta && partial && workspace && coef, "%s: NULL argument", who);
+    FIE_REQUIRE(C > 0 && C % 8 == 0 && B > 0 && groups > 0 && C % groups == 0 && rows_per_image > 0 && rows_per_image % 32 == 0,
+                "%s: bad shape C=%d G=%d rows=%lld", who, C, groups, (long long)rows_per_image);
+    FIE_REQUIRE(partial_groups == 0 || partial_groups == groups || (partial_groups > groups && partial_groups % groups == 0 && partial_groups * 4 == C),
+                "%s: partial_groups=%d must be 0, the group count, or C / 4 quads divisible into the %d groups", who, partial_groups, groups);
+    GnArgs p = {};
+    p.C1 = C; p.C = C; p.G = groups; p.cg = C / groups; p.rows = rows_per_image;
+    p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.eps = eps;
+    p.stats = (float*)workspace + (int64_t)B * GN_MAX_CHUNKS * groups * 2;
+    const int ngran = (int)(rows_per_image / 32);
+    if (ngran >= 4096 && groups <= 256 && 256 % groups == 0 && partial_groups <= groups) {        // as groupnorm_stats_t: gather, then the ordinary finalize
+        const int nb = 256, per = (ngran + nb - 1) / nb;
+        GnArgs g2 = p;
+        g2.partial = (float*)workspace;
+        g2.nchunks = nb;
+        FIE_DESC(ctx, "groupnorm gather-granules B=%d rows=%lld C=%d G=%d bytes=%.0f", B, (long long)rows_per_image, C, groups, 8.0 * B * ngran * groups);
+        fie_launch(ctx, gn_gather_granules_kernel<half_t>, dim3(nb, B), dim3(256), 0, g2, (const float*)partial, ngran, per);
+        FIE_DESC(ctx, "groupnorm finalize B=%d rows=%lld C=%d G=%d bytes=0", B, (long long)rows_per_image, C, groups);
+        fie_launch(ctx, gn_finalize_kernel<half_t>, dim3((B * groups + 3) / 4), dim3(256), 0, g2, B);
+    } else {
+        GnArgs f = p;
+        f.partial = const_cast<float*>((const float*)partial);
+        f.nchunks = ngran;
+        f.pg = partial_groups;
+        FIE_DESC(ctx, "groupnorm finalize-from-epilogue B=%d rows=%lld C=%d G=%d bytes=0", B, (long long)rows_per_image, C, groups);
+        fie_launch(ctx, gn_finalize_wide_kernel<half_t>, dim3(B * groups), dim3(256), 0, f, B);
+    }
+    FIE_DESC(ctx, "groupnorm coefficients B=%d rows=%lld C=%d G=%d bytes=0", B, (long long)rows_per_image, C, groups);
+    fie_launch(ctx, gn_coef_kernel<half_t>, dim3((C + 255) / 256, B), dim3(256), 0, p, coef);
+    FIE_LAUNCH_CHECK();
+    return FIE_OK;
+}
 
 int64_t fie_gn_stats_bytes(int B, int64_t rows_per_image, int groups) { return (int64_t)B * (rows_per_image / 32) * groups * 2 * (int64_t)sizeof(float); }
 

@@ -62,6 +62,9 @@ SIGNATURES = {
     "fie_attention_f16_o8": [_P, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _I, _F],
     "fie_quantize_f8": [_P, _P, _L, _P, _L, _L, _I, _F],
     "fie_amax_f16": [_P, _P, _L, _L, _I, _P],
+    "fie_groupnorm_coef_f16": [_P, _I, _I, _L, _I, _P, _P, _F, _P, _P, _I, _P],
+    "fie_conv3x3_gn_ok": [_P, _I, _I, _I, _I, _I, _I],
+    "fie_conv3x3_gn_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P, _I, _P, _L, _P, _L, _I, _P, _P, _L],
     "fie_canny_rgb_device_begin_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "fie_canny_rgb_device_finish_u8": [_P, _I, _I, _P, _P, _P, _P],
     "fie_weights_clear_prefix": [_P, _c.c_char_p],
@@ -281,6 +284,9 @@ class Context:
         # fp8 ACTIVATIONS for the transformer-block projections of an fp8-weight model (csrc/gemm_x8.hip): the producers (LayerNorm, attention,
         # the GEGLU epilogue) write e4m3 and the GEMMs run the block-scaled MFMA.  FIE_A8=0 keeps fp16 activations (round-2 behaviour: A/B)
         self.a8 = os.environ.get("FIE_A8", "1") != "0"
+        # GroupNorm + SiLU applied by the consuming halo conv (conv3x3_gn): built, bit-exact, and 20-70 % SLOWER than the two launches (the transform's
+        # exp / rcp do not fit the issue slots the MFMA segments leave: profiles/r04_gn_apply_in_the_halo_conv_negative.log) -- off unless FIE_GN_FUSE_CONV=1
+        self.gn_fuse_conv = os.environ.get("FIE_GN_FUSE_CONV", "0") == "1"
         self.calib = False             # True during HipImg2ImgPipeline.calibrate_fp8: fp8-activation layers run f16 activations and record max |x|
         # Tile / split-K choices from a file (include/fie.h: fie_gemm_autotune_load): FIE_TUNE_TABLE=<report of an earlier process>.  With
         # FIE_TUNE_FROZEN=1 the pipelines never time anything new (shapes outside the table use the built-in rule): one choice per shape on
@@ -720,6 +726,45 @@ class Context:
             return out
         _chk((lib().fie_groupnorm_nhwc_f32 if self.f32 else lib().fie_groupnorm_nhwc_f16)(self.h, _p(x1), c1, _p(x2), c2, _p(out), b, rows, groups, _p(gamma),
                                           _p(beta), float(eps), int(silu), _p(ws)))
+        return out
+
+    def conv3x3_gn_ok(self, x, cout, out_groups):
+        """True when GroupNorm(+SiLU) -> conv3x3 exists as ONE launch for this input (include/fie.h: fie_conv3x3_gn_ok) and x carries its producer's sums."""
+        b, h, w, cin = x.shape
+        return bool(self.gn_fuse_conv and not self.f32 and getattr(x, "_gn_tag", None) is not None and out_groups
+                    and lib().fie_conv3x3_gn_ok(self.h, b, h, w, cin, cout, out_groups))
+
+    def groupnorm_coef(self, x, gamma, beta, groups, eps):
+        """The GroupNorm of x (which carries its producer's partial sums) as per-(image, channel) coefficients [B, C, 2] f32 (fie_groupnorm_coef_f16), or
+        None when the sums are not there any more."""
+        self.sync_stream()
+        b, rows, c = x.shape[0], x[0].numel() // x.shape[-1], x.shape[-1]
+        tag = getattr(x, "_gn_tag", None)
+        key = (self._stream, self.ws_tag)
+        if not (tag is not None and tag[1:5] == (groups, c, rows, b) and tag[5] == self._gn_gen and tag[6] == key):
+            return None
+        need = lib().fie_groupnorm_workspace_bytes(b, rows, groups)
+        ws = self._gn_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._gn_ws[key] = torch.empty(need, device=self.device, dtype=torch.uint8)
+        if self._keep is not None:
+            self._keep.append(ws)
+        coef = self._alloc((b, c, 2), torch.float32)
+        _chk(lib().fie_groupnorm_coef_f16(self.h, c, b, rows, groups, _p(gamma), _p(beta), float(eps), _p(tag[0]), _p(ws), tag[7], _p(coef)))
+        return coef
+
+    def conv3x3_gn(self, x, coef, silu, wp, cout, bias=None, residual=None, gn_groups=None):
+        """conv3x3(silu(x * sc + sh)) in one launch (fie_conv3x3_gn_nhwc_f16); the output's own GroupNorm sums are armed as for conv3x3."""
+        self.sync_stream()
+        self._bind_splitk()
+        b, h, w, cin = x.shape
+        assert x.is_contiguous() and coef.dtype == torch.float32 and coef.shape == (b, cin, 2)
+        out = self._alloc((b, h, w, cout))
+        tag = self._gn_stats_arm(b * h * w, cout, h * w, gn_groups)
+        assert tag is not None, "the fused GroupNorm -> conv needs the output's sums armed (conv3x3_gn_ok)"
+        _chk(lib().fie_conv3x3_gn_nhwc_f16(self.h, _p(x), b, h, w, cin, _p(coef), int(bool(silu)), _p(wp), wp.stride(0), _p(out), out.stride(2), cout, _p(bias),
+                                           _p(residual), residual.stride(2) if residual is not None else 0))
+        out._gn_tag = tag
         return out
 
     def quantize_f8(self, x, inv_scale=1.0):

@@ -107,8 +107,28 @@ class Resnet:
                 zero = torch.zeros(self.c2.n, dtype=self.c2.wp.dtype, device=self.c2.wp.device)
                 self.b_plus = (self.c2.b if self.c2.b is not None else zero) + (self.sc.b if self.sc.b is not None else zero)
 
+    def _gn_conv(self, ctx, x, norm, conv, residual=None):
+        """GroupNorm + SiLU + conv3x3 as ONE launch where the halo-resident kernel has that form (include/fie.h: fie_conv3x3_gn_nhwc_f16: one image, 16-aligned
+        map, 128..1024 input channels, x carrying its producer's sums): the conv normalises its input in LDS and the apply kernel's read + write of the
+        tensor disappear.  None: not built for this conv -- the caller takes the two launches."""
+        if not (torch.is_tensor(conv.wp) and conv.wp.dtype == torch.float16 and conv.cin_pad == conv.cin == x.shape[-1] and conv.ldc <= conv.n == conv.cout
+                and ctx.conv3x3_gn_ok(x, conv.n, self.groups)):
+            return None
+        coef = ctx.groupnorm_coef(x, norm.g, norm.b, self.groups, self.eps)
+        if coef is None:
+            return None
+        return ctx.conv3x3_gn(x, coef, True, conv.wp, conv.n, bias=conv.b, residual=residual, gn_groups=self.groups)
+
     def __call__(self, ctx, x, temb_all=None, skip=None):
         b, h, w, _ = x.shape
+        if skip is None and self.temb_slot is None and not ctx.calib:      # the VAE's resnets: both convs may take their GroupNorm along
+            y = self._gn_conv(ctx, x, self.n1, self.c1)
+            if y is not None:
+                if self.sc is None:
+                    out = self._gn_conv(ctx, y, self.n2, self.c2, residual=x)
+                    if out is not None:
+                        return out
+                return self._tail(ctx, x, y, skip)
         calib = ctx.calib and self.amax is not None             # calibration pass: f16 activations (the fp8-weight kernels take them), max |x| recorded
         q1, q2 = self.c1.a8 and not calib, self.c2.a8 and self.wp_plus is None and not calib
         y = ctx.groupnorm(x, self.n1.g, self.n1.b, self.groups, self.eps, True, x2=skip, out_f8=q1, out_inv_scale=1.0 / self.s8[0])   # fp8 model: e4m3 for an fp8-activation conv
@@ -116,6 +136,11 @@ class Resnet:
             ctx.amax_into(y, self.amax[0:1])
         rb = temb_all[:, self.temb_slot[0]:self.temb_slot[1]] if self.temb_slot is not None else None
         y = self.c1(ctx, y, rowbias=rb, gn_groups=self.groups, a_scale=self.s8[0] if q1 else 1.0)     # norm2's first pass rides on conv1's epilogue where the group width allows
+        return self._tail(ctx, x, y, skip, calib, q2)
+
+    def _tail(self, ctx, x, y, skip, calib=False, q2=False):
+        """norm2 -> SiLU -> conv2 (+ shortcut | identity) on conv1's output y."""
+        b, h, w, _ = x.shape
         y = ctx.groupnorm(y, self.n2.g, self.n2.b, self.groups, self.eps, True, out_f8=q2, out_inv_scale=1.0 / self.s8[1])
         if calib and self.c2.a8 and self.wp_plus is None:
             ctx.amax_into(y, self.amax[1:2])

@@ -418,6 +418,20 @@ int fie_conv_up2x_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int
  * border) and pass partial_groups = N / 4 to fie_groupnorm_stats_nhwc_f16, which sums the N / 4 / groups quads of each real group
  * (partial_groups 0 or == groups: slots are groups, as above). */
 int fie_gn_stats_target(fie_ctx* ctx, void* partial, int64_t rows_per_image, int groups);
+/* GroupNorm (+ SiLU) FUSED INTO THE CONSUMING 3x3 CONV (round 4; upstream models/resnet.py: norm1 -> nonlinearity -> conv1, norm2 -> nonlinearity -> conv2).
+ * fie_groupnorm_coef_f16 finishes the statistics a producer's epilogue left (as fie_groupnorm_stats_nhwc_f16 does) but writes, instead of a normalised
+ * tensor, coef[B][C][2] floats: (sc, sh) = (rstd * gamma, beta - mean * rstd * gamma).  fie_conv3x3_gn_nhwc_f16 is the same-size stride-1 3x3 conv of
+ * silu(X * sc + sh) (silu optional): the halo-resident kernel applies the expression to every 64-channel chunk of a 16x16 patch's halo while it sits in LDS,
+ * behind the MFMAs of the chunk before; padding pixels stay zero (the conv pads the NORMALISED tensor).  Same fp32 expression as the apply kernel: the
+ * result has the bits of fie_groupnorm_stats_nhwc_f16 followed by fie_conv3x3_nhwc_f16 on tile code 72, without the read + write of the normalised tensor.
+ * Built for what fie_conv3x3_gn_ok returns 1 for (one image, H, W % 16 == 0, Cin in whole 64-channel chunks from 128 to 1024, Cout % 128 == 0) WITH a
+ * fie_gn_stats_target armed for the OUTPUT at 4 / 8 / 16 channels per group (out_groups) -- every resnet conv of the VAE; elsewhere the caller keeps the two
+ * launches.  workspace as for fie_groupnorm_nhwc_f16. */
+int fie_groupnorm_coef_f16(fie_ctx* ctx, int C, int B, int64_t rows_per_image, int groups, const void* gamma, const void* beta, float eps, const void* partial,
+                           void* workspace, int partial_groups, float* coef);
+int fie_conv3x3_gn_ok(fie_ctx* ctx, int B, int H, int W, int Cin, int Cout, int out_groups);
+int fie_conv3x3_gn_nhwc_f16(fie_ctx* ctx, const void* X, int B, int H, int W, int Cin, const float* coef, int silu, const void* Wpacked, int64_t ldw, void* Y,
+                            int64_t ldc, int Cout, const void* bias, const void* residual, int64_t ldr);
 int64_t fie_gn_stats_bytes(int B, int64_t rows_per_image, int groups);
 int fie_groupnorm_stats_nhwc_f16(fie_ctx* ctx, const void* X, int C, void* Y, int B, int64_t rows_per_image, int groups, const void* gamma,
                                  const void* beta, float eps, int silu, const void* partial, void* workspace, int partial_groups);

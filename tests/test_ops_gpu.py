@@ -619,6 +619,58 @@ def test_halo_resident_conv(fie, code):
         fie.force_tile(0)
 
 
+def test_groupnorm_fused_into_the_halo_conv(fie):
+    """GroupNorm + SiLU -> conv3x3 as ONE launch (include/fie.h: fie_groupnorm_coef_f16 + fie_conv3x3_gn_nhwc_f16; csrc/conv_halo.hip, GNA): the conv reads
+    the un-normalised tensor and normalises every halo chunk in LDS.  Against the two-launch sequence on the same kernel family (GroupNorm from the
+    producer's sums, then the conv on tile code 72): bit for bit, the output's own GroupNorm sums included; with and without a residual, 128 to 1024 input
+    channels, one and several tiles per block, a map whose patches touch all four borders; repeats bit-identical; against torch fp32 to rounding."""
+    from fie_amd import hip
+    g = torch.Generator().manual_seed(77)
+    fuse0, fie.gn_fuse_conv = fie.gn_fuse_conv, True      # the product leaves this form off (measured slower: profiles/r04_gn_apply_in_the_halo_conv_negative.log); the op is kept correct
+    try:
+        for h, w, cin, cout, use_res in [(320, 320, 128, 128, True), (160, 160, 256, 256, False), (128, 160, 512, 256, True), (64, 64, 1024, 128, False),
+                                         (32, 48, 128, 128, False), (16, 16, 256, 128, True)]:
+            x0 = torch.randn(1, h, w, 64, generator=g).half().to(DEV)
+            w0 = (torch.randn(cin, 64, 3, 3, generator=g) * (9 * 64) ** -0.5).half().to(DEV)
+            wt = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half().to(DEV)
+            b0, b1 = torch.randn(cin, generator=g).half().to(DEV), torch.randn(cout, generator=g).half().to(DEV)
+            gam, bet = (1 + 0.3 * torch.randn(cin, generator=g)).half().to(DEV), (0.2 * torch.randn(cin, generator=g)).half().to(DEV)
+            res = torch.randn(1, h, w, cout, generator=g).half().to(DEV) if use_res else None
+            wp0, wp = fie.pack_conv3x3(w0), fie.pack_conv3x3(wt)
+            fie.force_tile(0)
+            x = fie.conv3x3(x0, wp0, cin, bias=b0, gn_groups=32)                    # a producer that leaves its sums on x
+            fie.force_tile(72)
+            ref = fie.conv3x3(fie.groupnorm(x, gam, bet, 32, 1e-6, True), wp, cout, bias=b1, residual=res, gn_groups=32)
+            ref_gn = fie.groupnorm(ref, torch.ones(cout).half().to(DEV), torch.zeros(cout).half().to(DEV), 32, 1e-6, False)
+            fie.force_tile(0)
+            outs = []
+            for _ in range(4):
+                x2 = fie.conv3x3(x0, wp0, cin, bias=b0, gn_groups=32)
+                assert torch.equal(x2, x) and fie.conv3x3_gn_ok(x2, cout, 32)
+                coef = fie.groupnorm_coef(x2, gam, bet, 32, 1e-6)
+                outs.append(fie.conv3x3_gn(x2, coef, True, wp, cout, bias=b1, residual=res, gn_groups=32))
+                assert "conv_halo2" in hip.last_gemm_kernel(fie)
+            got_gn = fie.groupnorm(outs[-1], torch.ones(cout).half().to(DEV), torch.zeros(cout).half().to(DEV), 32, 1e-6, False)
+            tiles = (h // 16) * (w // 16) * (cout // 128)
+            if tiles > 256:                                                         # the two-launch reference ran the same persistent kernel: same bits
+                assert torch.equal(outs[0], ref) and torch.equal(got_gn, ref_gn), (h, w, cin, cout, use_res)
+            else:                                                                   # it ran the one-tile-per-block form: another epilogue, same sums to rounding
+                assert rel_err(outs[0], ref.float()) < 2e-3 and rel_err(got_gn, ref_gn.float()) < 4e-3, (h, w, cin, cout, use_res)
+            assert all(torch.equal(o, outs[0]) for o in outs[1:]), (h, w, cin, cout, use_res)
+            y32 = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), 32, gam.float(), bet.float(), 1e-6))
+            t32 = F.conv2d(y32, wt.float(), b1.float(), padding=1) + (res.float().permute(0, 3, 1, 2) if use_res else 0)
+            assert rel_err(outs[0].permute(0, 3, 1, 2), t32) < 4e-3, (h, w, cin, cout, use_res)
+        # where the fused form is not built the query says so (and the entry refuses): two images, a 24-pixel map, 64 input channels
+        x = torch.randn(2, 32, 32, 128, generator=g).half().to(DEV)
+        x._gn_tag = ("x",)
+        assert not fie.conv3x3_gn_ok(x, 128, 32)
+        assert not hip.lib().fie_conv3x3_gn_ok(fie.h, 1, 24, 32, 128, 128, 32) and not hip.lib().fie_conv3x3_gn_ok(fie.h, 1, 32, 32, 64, 128, 32)
+        assert not hip.lib().fie_conv3x3_gn_ok(fie.h, 1, 32, 32, 128, 320, 32)
+    finally:
+        fie.force_tile(0)
+        fie.gn_fuse_conv = fuse0
+
+
 def test_halo_resident_conv_with_1x1_side_inputs(fie):
     """A resnet's conv2 + its 1x1 shortcut as one launch (include/fie.h: fie_conv3x3_plus_nhwc_f16) on the halo-resident kernel (code 72): the side
     inputs run as centre-tap K-steps behind the nine-tap chunks.  Against torch fp32; one and several tiles per block, one and two side inputs,

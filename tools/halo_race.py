@@ -50,5 +50,36 @@ for b, h, cin, cout, opts in [(1, 1024, 128, 128, "bias,res,gn"), (1, 1024, 128,
     ctx.force_tile(0)
     print(f"{name}: B={b} {h}x{h} {cin}->{cout} [{opts}]: {diffs} of {reps} repeats differ", flush=True)
     bad += diffs
+# the fused GroupNorm -> conv form (GNA: the halo is normalised in LDS by the lane that DMA'd it): the input's sums come from a producer conv each time
+for h, cin, cout, use_res in [(1024, 128, 128, True), (512, 256, 256, False), (256, 512, 512, True), (1024, 256, 128, False)]:
+    x0 = torch.randn(1, h, h, 64, generator=g, device=DEV, dtype=torch.float16)
+    wp0 = ctx.pack_conv3x3(torch.randn(cin, 64, 3, 3, generator=g, device=DEV, dtype=torch.float16) * (9 * 64) ** -0.5)
+    wp = ctx.pack_conv3x3(torch.randn(cout, cin, 3, 3, generator=g, device=DEV, dtype=torch.float16) * (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=g, device=DEV, dtype=torch.float16)
+    gam = (1 + 0.3 * torch.randn(cin, generator=g, device=DEV)).half()
+    bet = (0.2 * torch.randn(cin, generator=g, device=DEV)).half()
+    res = torch.randn(1, h, h, cout, generator=g, device=DEV, dtype=torch.float16) if use_res else None
+    a2 = torch.randn(4096, 1280, generator=g, device=DEV, dtype=torch.float16)
+    w2 = ctx.pack_linear(torch.randn(1280, 1280, generator=g, device=DEV, dtype=torch.float16) * 0.03)
+
+    def fused():
+        x = ctx.conv3x3(x0, wp0, cin, gn_groups=32)
+        coef = ctx.groupnorm_coef(x, gam, bet, 32, 1e-6)
+        return ctx.conv3x3_gn(x, coef, True, wp, cout, bias=bias, residual=res, gn_groups=32)
+
+    first = fused().clone()
+    name = hip.last_gemm_kernel(ctx)
+    torch.cuda.synchronize()
+    diffs = 0
+    for it in range(reps):
+        if it % 2:
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    ctx.gemm(a2, w2, 1280)
+        y = fused()
+        torch.cuda.synchronize()
+        diffs += int(not torch.equal(y, first))
+    print(f"{name} + GroupNorm of the input in LDS: 1 {h}x{h} {cin}->{cout} [bias,gn{',res' if use_res else ''}]: {diffs} of {reps} repeats differ", flush=True)
+    bad += diffs
 print("RACE SCREEN", "FAILED" if bad else "clean")
 sys.exit(1 if bad else 0)
