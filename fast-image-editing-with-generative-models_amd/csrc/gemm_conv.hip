@@ -12,7 +12,7 @@
 //   gemm8_kernel<MODE> (gemm8.hip)   256x256, four phases per K-tile, two wave groups one barrier apart.
 //
 // Unselected experiments of round 1 (zero-page global_load_lds ring, ping-pong, four-phase, producer waves, halo-reuse conv,
-// 160-wide tiles, column split) are archived, unbuilt, in tools/experiments/gemm_variants_r01.hip.
+// 160-wide tiles, column split): measured no better, removed (git history has them; the numbers are in profiles/r01_microbench.md).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
