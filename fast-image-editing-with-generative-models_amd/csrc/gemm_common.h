@@ -55,6 +55,10 @@ struct GemmArgs {
     // (16 pixels of one patch row) then starts frag_ld = OW rows after fragment j - 1 instead of 16: the epilogue's row of fragment (wm, j), lane fr
     // is m0 + (wm * FM + j) * frag_ld + fr with m0 = the patch's first pixel.  0 = the ordinary consecutive-row tile (16).
     int frag_ld;
+    // LayerNorm folded into the GEMM (fie_gemm_ln_f16; ring tiles 42 / 48 / 96 / 64, LEAN == 2): A1 is the UN-normalised tensor, Wt = W * gamma, and with
+    // (mean, rstd) of row m -- summed over the activation fragments on their way to the MFMAs -- C[m, n] = rstd * (acc - mean * ln_tab[n][0]) + ln_tab[n][1],
+    // ln_tab[n] = (sum_k Wt[n, k], (W beta)[n] + bias[n]) in fp32 (packed column order).  NULL: none
+    const float* ln_tab; float ln_eps;
     const float* gna_tab; int gna_silu;        // conv_halo.hip, GNA: per-(image, channel) GroupNorm coefficients (sc, sh) of the conv's INPUT (fie_groupnorm_coef_f16), applied on the resident halo
 };
 
@@ -190,6 +194,53 @@ __device__ __forceinline__ void epilogue_lean_scaled(const GemmArgs& p, f32x4 (&
     }
 }
 
+// ---- LayerNorm folded into the consumer GEMM (GemmArgs::ln_tab).  LN(x) W^T = rstd * (x (W gamma)^T - mean * colsum(W gamma)) + W beta: the
+// normalised tensor is never written or read.  The row sums come from the activation fragments the MFMAs consume anyway: in the swapped operand
+// layout lane (fr, fq) holds 8 k-values of row fr, the row it also owns in the epilogue; two v_dot2c_f32_f16 per register pair (x . 1, x . x).
+__device__ __forceinline__ void ln_dot(const f16x8& f, float& s, float& q) {
+    const f16x2 one = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f16x2 v = {f[2 * t], f[2 * t + 1]};
+        s = __builtin_amdgcn_fdot2(v, one, s, false);
+        q = __builtin_amdgcn_fdot2(v, v, q, false);
+    }
+}
+
+// (colsum, bias') pairs of a lane's 4 columns of fragment column i: 32 contiguous bytes, two 16-byte buffer loads; columns >= N read zero
+template <int FN>
+struct LnTab { f32x4 lo[FN], hi[FN]; };       // lo = (S0, b0, S1, b1), hi = (S2, b2, S3, b3)
+__device__ __forceinline__ void ln_tab_load(const GemmArgs& p, int n, f32x4& lo, f32x4& hi) {
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.ln_tab), 0, p.N * 8, 0x00020000);
+    lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, (unsigned)n * 8u, 0, 0));
+    hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, (unsigned)n * 8u + 16u, 0, 0));
+}
+
+template <int FM, int FN, int WM, int WN>
+__device__ __forceinline__ void epilogue_lean_ln(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane, const LnTab<FN>& tab,
+                                                 const float (&mean)[FM], const float (&rstd)[FM]) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int mrow = m0 + wm * WM + fr, ncol = n0 + wn * WN + fq * 4;
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = mrow + j * 16;
+        const unsigned ro = m < p.M ? (unsigned)m * (unsigned)p.ldc * 2u : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int n = ncol + i * 16;
+            f16x4 o;
+            o[0] = (half_t)((acc[i][j][0] - mean[j] * tab.lo[i][0]) * rstd[j] + tab.lo[i][1]);
+            o[1] = (half_t)((acc[i][j][1] - mean[j] * tab.lo[i][2]) * rstd[j] + tab.lo[i][3]);
+            o[2] = (half_t)((acc[i][j][2] - mean[j] * tab.hi[i][0]) * rstd[j] + tab.hi[i][1]);
+            o[3] = (half_t)((acc[i][j][3] - mean[j] * tab.hi[i][2]) * rstd[j] + tab.hi[i][3]);
+            u32x2 bits;
+            __builtin_memcpy(&bits, &o, 8);
+            __builtin_amdgcn_raw_buffer_store_b64(bits, rs_c, ro + (n < p.N ? (unsigned)n << 1 : 0xC0000000u), 0, 0);
+        }
+    }
+}
+
 // The LEAN GEGLU epilogue of the big tiles (256x320: the FF1 projection): bias + value * gelu(gate) -> f16 pairs, nothing else compiled in; same
 // arithmetic as the full epilogue with scale 1.  The full path of these tiles inlines the generic epilogue three times.
 // Stores (round 4): a lane's two outputs of a fragment are 4 bytes; stored as they are, every instruction leaves 16 bytes in each of 16 rows and the
@@ -197,8 +248,10 @@ __device__ __forceinline__ void epilogue_lean_scaled(const GemmArgs& p, f32x4 (&
 // v_permlane16_swap + two v_permlane32_swap) regroups them: over four fragment COLUMNS lane row q ends up with the 16 contiguous bytes of column I0 + q, so
 // one 16-byte store per lane writes 64 contiguous bytes per row; the columns left over (FN % 4) are transposed over four ROW fragments instead (16-byte
 // stores, 16 bytes per row: fewer instructions, same sectors).
-template <int FM, int FN, int WM, int WN>
-__device__ __forceinline__ void epilogue_geglu_lean(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane) {
+// LN: the LayerNorm-folded form (above): value / gate = rstd * (acc - mean * S) + b' from the fp32 table instead of acc + bias
+template <int FM, int FN, int WM, int WN, bool LN = false>
+__device__ __forceinline__ void epilogue_geglu_lean(const GemmArgs& p, f32x4 (&acc)[FN][FM], int m0, int n0, int wm, int wn, int lane,
+                                                    const float* mean = nullptr, const float* rstd = nullptr) {
     static_assert(FM % 4 == 0, "left-over fragment columns are transposed over four row fragments");
     const int fr = lane & 15, fq = lane >> 4;
     const int mrow = m0 + wm * WM + fr, nbase = n0 + wn * WN;
@@ -222,31 +275,65 @@ __device__ __forceinline__ void epilogue_geglu_lean(const GemmArgs& p, f32x4 (&a
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(r1), "+v"(r3));
     };
     auto rowoff = [&](int m) { return m < p.M ? (unsigned)m * (unsigned)p.ldc * 2u : 0x80000000u; };
+    // LN: one fragment's four columns (value, gate, value, gate) un-normalised -> normalised, then the same product
+    struct Tab { f32x4 lo, hi; };
+    auto tab4 = [&](int i) { Tab t; ln_tab_load(p, nbase + i * 16 + fq * 4, t.lo, t.hi); return t; };
+    auto pair_ln = [&](const f32x4& a, const Tab& t, int j) {
+        const float mu = mean[j], rs = rstd[j];
+        f16x2 o;
+        o[0] = (half_t)(((a[0] - mu * t.lo[0]) * rs + t.lo[1]) * fie_gelu((a[1] - mu * t.lo[2]) * rs + t.lo[3]) * 1.0f);
+        o[1] = (half_t)(((a[2] - mu * t.hi[0]) * rs + t.hi[1]) * fie_gelu((a[3] - mu * t.hi[2]) * rs + t.hi[3]) * 1.0f);
+        unsigned bits;
+        __builtin_memcpy(&bits, &o, 4);
+        return bits;
+    };
     // a value / gate column n is output column n / 2, two bytes each: byte offset n
     static_for([&](auto gc) {                                 // four fragment columns at a time: this lane stores column I0 + fq
         constexpr int I0 = 4 * decltype(gc)::value;
-        const u32x2 b0 = bias4(I0), b1 = bias4(I0 + 1), b2 = bias4(I0 + 2), b3 = bias4(I0 + 3);
         const int nst = nbase + (I0 + fq) * 16;
         const unsigned co = nst < p.N ? (unsigned)nst : 0xC0000000u;
+        if constexpr (LN) {
+            const Tab t0 = tab4(I0), t1 = tab4(I0 + 1), t2 = tab4(I0 + 2), t3 = tab4(I0 + 3);
 #pragma unroll
-        for (int j = 0; j < FM; ++j) {
-            unsigned r0 = pair(acc[I0][j], b0), r1 = pair(acc[I0 + 1][j], b1), r2 = pair(acc[I0 + 2][j], b2), r3 = pair(acc[I0 + 3][j], b3);
-            transpose4(r0, r1, r2, r3);
-            const u32x4 v = {r0, r1, r2, r3};
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, rowoff(mrow + j * 16) + co, 0, 0);
+            for (int j = 0; j < FM; ++j) {
+                unsigned r0 = pair_ln(acc[I0][j], t0, j), r1 = pair_ln(acc[I0 + 1][j], t1, j), r2 = pair_ln(acc[I0 + 2][j], t2, j), r3 = pair_ln(acc[I0 + 3][j], t3, j);
+                transpose4(r0, r1, r2, r3);
+                const u32x4 v = {r0, r1, r2, r3};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, rowoff(mrow + j * 16) + co, 0, 0);
+            }
+        } else {
+            const u32x2 b0 = bias4(I0), b1 = bias4(I0 + 1), b2 = bias4(I0 + 2), b3 = bias4(I0 + 3);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                unsigned r0 = pair(acc[I0][j], b0), r1 = pair(acc[I0 + 1][j], b1), r2 = pair(acc[I0 + 2][j], b2), r3 = pair(acc[I0 + 3][j], b3);
+                transpose4(r0, r1, r2, r3);
+                const u32x4 v = {r0, r1, r2, r3};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, rowoff(mrow + j * 16) + co, 0, 0);
+            }
         }
     }, std::make_integer_sequence<int, FN / 4>{});
     static_for([&](auto ic) {                                 // the columns left over: four row fragments at a time, this lane stores row fragment 4 h + fq
         constexpr int I = FN / 4 * 4 + decltype(ic)::value;
-        const u32x2 b = bias4(I);
         const int n = nbase + I * 16;
         const unsigned co = n < p.N ? (unsigned)n : 0xC0000000u;
+        if constexpr (LN) {
+            const Tab t = tab4(I);
 #pragma unroll
-        for (int h = 0; h < FM / 4; ++h) {
-            unsigned r0 = pair(acc[I][4 * h], b), r1 = pair(acc[I][4 * h + 1], b), r2 = pair(acc[I][4 * h + 2], b), r3 = pair(acc[I][4 * h + 3], b);
-            transpose4(r0, r1, r2, r3);
-            const u32x4 v = {r0, r1, r2, r3};
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, rowoff(mrow + (4 * h + fq) * 16) + co, 0, 0);
+            for (int h = 0; h < FM / 4; ++h) {
+                unsigned r0 = pair_ln(acc[I][4 * h], t, 4 * h), r1 = pair_ln(acc[I][4 * h + 1], t, 4 * h + 1), r2 = pair_ln(acc[I][4 * h + 2], t, 4 * h + 2), r3 = pair_ln(acc[I][4 * h + 3], t, 4 * h + 3);
+                transpose4(r0, r1, r2, r3);
+                const u32x4 v = {r0, r1, r2, r3};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, rowoff(mrow + (4 * h + fq) * 16) + co, 0, 0);
+            }
+        } else {
+            const u32x2 b = bias4(I);
+#pragma unroll
+            for (int h = 0; h < FM / 4; ++h) {
+                unsigned r0 = pair(acc[I][4 * h], b), r1 = pair(acc[I][4 * h + 1], b), r2 = pair(acc[I][4 * h + 2], b), r3 = pair(acc[I][4 * h + 3], b);
+                transpose4(r0, r1, r2, r3);
+                const u32x4 v = {r0, r1, r2, r3};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, rowoff(mrow + (4 * h + fq) * 16) + co, 0, 0);
+            }
         }
     }, std::make_integer_sequence<int, FN % 4>{});
 }

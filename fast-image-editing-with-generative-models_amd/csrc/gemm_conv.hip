@@ -173,8 +173,11 @@ __device__ __forceinline__ void read_frags(f16x8 (&f)[N], unsigned addr, std::in
 // A K-step of these kernels is a serial sum -- DMA issue (the waves sit in the 64 B/clk load path) + fragment reads + MFMAs + barrier -- because every
 // wave does the same thing at the same time; with turns, the group that issues nothing goes straight to its reads and MFMAs while the other one feeds the
 // load path, and in the next K-step they swap.
-template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false, bool ALT = false, bool LEAN = false>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0
+// LEAN: 0 = the full epilogue, 1 = the lean one (plain Linear), 2 = LayerNorm folded in (GemmArgs::ln_tab: row sums from the activation fragments, lean LN epilogues)
+template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false, bool ALT = false, int LEAN = 0>    // MODE 0 = GEMM, 2 = conv with Cin % 64 == 0
 __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
+    constexpr bool LNF = LEAN == 2;
+    static_assert(!LNF || (MODE == 0 && !STAMP), "LayerNorm fold: GEMM view only");
     static_assert(!ALT || (NW == 8 && MODE == 0 && !PF && !STAMP), "ALT: 8-wave GEMM-view tiles without the fragment prefetch");
     // waves as 2 (rows) x NW/2 (columns) wherever that leaves whole 16-column fragments; otherwise (128x80) all NW waves stacked along the rows
     constexpr int WGN = (BN / (NW / 2)) % 16 == 0 ? NW / 2 : 1, WGM = NW / WGN;
@@ -341,9 +344,29 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     // bias row + residual tile go out ahead of the ring's first stage and are complete (loads return in order) by the first counted wait
     EpiPre<FM, FN> pre;
     pre.on = false;
+    LnTab<(LNF && FM * FN <= 16) ? FN : 1> ln_pre;
     if constexpr (FM * FN <= 16) {
-        if (LEAN || (nsplit == 1 && p.epi_prefetch)) epilogue_prefetch<FM, FN, WM, WN>(p, pre, m0, n0, wm, wn, lane);
+        if constexpr (LNF) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i) ln_tab_load(p, n0 + wn * WN + i * 16 + (lane >> 4) * 4, ln_pre.lo[i], ln_pre.hi[i]);
+        } else if (LEAN || (nsplit == 1 && p.epi_prefetch)) epilogue_prefetch<FM, FN, WM, WN>(p, pre, m0, n0, wm, wn, lane);
     }
+    // LNF: the WGN waves that read the same activation fragments share the statistics work: wave column wn sums row fragments j with j % WGN == wn
+    static_assert(!LNF || FM % WGN == 0, "row fragments are dealt to the wave columns");
+    constexpr int LJ = LNF ? FM / WGN : 1;
+    float ln_s[LJ], ln_q[LJ];
+#pragma unroll
+    for (int t = 0; t < LJ; ++t) ln_s[t] = ln_q[t] = 0.f;
+    // fragments fa[0 .. CNT) are row fragments J0 .. J0 + CNT of the wave tile
+    auto ln_take = [&](auto j0c, auto cntc, const f16x8* fa) {
+        if constexpr (LNF) {
+            static_for([&](auto jc) {
+                constexpr int j = decltype(j0c)::value + decltype(jc)::value;
+                if (WGN == 1 || j % WGN == wn) ln_dot(fa[decltype(jc)::value], ln_s[j / WGN], ln_q[j / WGN]);
+            }, std::make_integer_sequence<int, decltype(cntc)::value>{});
+        }
+    };
+    using c0_t = std::integral_constant<int, 0>;
 
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
@@ -413,6 +436,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
             landed(fw0, fa0);
             mfmas(fw0, fa0);
+            ln_take(c0_t{}, std::integral_constant<int, FM>{}, fa0);
             if (more && NW == 8) issue_w(kbeg + kt + ST - 1, fill);
             stage = stage + 1 == ST ? 0 : stage + 1;
             fill = fill + 1 == ST ? 0 : fill + 1;
@@ -424,6 +448,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
                 reads(fw0, fa0, stage, 0);
             }
             mfmas(fw1, fa1);
+            ln_take(c0_t{}, std::integral_constant<int, FM>{}, fa1);
         }
     } else
     for (int kt = 0; kt < nk; ++kt) {
@@ -470,6 +495,8 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
 #pragma unroll
                         for (int j = 0; j < HM; ++j) acc[i][jh * HM + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][jh * HM + j], 0, 0, 0);
                     __builtin_amdgcn_s_setprio(0);
+                    if (jh == 0) ln_take(c0_t{}, std::integral_constant<int, HM>{}, fa);
+                    else ln_take(std::integral_constant<int, HM>{}, std::integral_constant<int, HM>{}, fa);
                 }
             } else {
                 f16x8 fw[FN], fa[FM];
@@ -477,6 +504,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
                 if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 stamp(2 + 3 * kk);                         // 2 / 5: fragment reads issued and landed
                 mfmas(fw, fa);
+                ln_take(c0_t{}, std::integral_constant<int, FM>{}, fa);
                 stamp(3 + 3 * kk);                         // 3 / 6: 16 MFMAs issued
             }
         }
@@ -484,9 +512,39 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         fill = fill + 1 == ST ? 0 : fill + 1;
     }
     stamp(11);                                             // last MFMA group issued
+    float ln_mean[LNF ? FM : 1], ln_rstd[LNF ? FM : 1];
+    if constexpr (LNF) {
+        // a lane holds the sums over its own k-slices (fq): total over the four fq lane rows, then the wave columns trade their row fragments
+        // through LDS (the ring is drained once every wave is past its last fragment read)
+#pragma unroll
+        for (int t = 0; t < LJ; ++t) {
+            ln_s[t] += __shfl_xor(ln_s[t], 16); ln_s[t] += __shfl_xor(ln_s[t], 32);
+            ln_q[t] += __shfl_xor(ln_q[t], 16); ln_q[t] += __shfl_xor(ln_q[t], 32);
+        }
+        __syncthreads();
+        float2* st = reinterpret_cast<float2*>(smem);
+        if (lane < 16) {
+#pragma unroll
+            for (int t = 0; t < LJ; ++t) st[wm * WM + (t * WGN + wn) * 16 + lane] = make_float2(ln_s[t], ln_q[t]);
+        }
+        __syncthreads();
+        const float inv_k = 1.f / (float)p.K;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const float2 v = st[wm * WM + j * 16 + (lane & 15)];
+            const float mu = v.x * inv_k;
+            ln_mean[j] = mu;
+            ln_rstd[j] = rsqrtf(fmaxf(v.y * inv_k - mu * mu, 0.f) + p.ln_eps);
+        }
+    }
     if constexpr (FM * FN <= 16 && !LEAN) {                // split-K: only the block that draws the tile's last ticket goes on, with the summed slices
         if (nsplit > 1 && !splitk_reduce<FM, FN, NW>(p, acc, tile_all, slice, tid, smem)) return;
     }
+    if constexpr (LNF && FM * FN > 16) {
+        epilogue_geglu_lean<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane, ln_mean, ln_rstd);      // host: GEGLU only on the big tile
+    } else if constexpr (LNF) {
+        epilogue_lean_ln<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane, ln_pre, ln_mean, ln_rstd);
+    } else
     if constexpr (FM * FN > 16) {                          // 256x256 / 256x320: column chunks of two fragments (register pressure, see gemm8.hip)
         if (p.act == FIE_ACT_GEGLU && p.epi_prefetch && !p.rowbias && !p.res && p.scale == 1.f && !p.gn_partial && !p.out_f8 && !p.w_scale && !p.oscat && p.probe == 0) {
             epilogue_geglu_lean<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane);         // the FF1 projection: compact code instead of three generic epilogues
@@ -502,7 +560,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             epilogue<FM, 1, WM, WN, true>(p, reinterpret_cast<f32x4(&)[1][FM]>(acc[FN - 1]), m0, n0 + 16 * (FN - 1), wm, wn, lane);
         }
     } else {
-        if constexpr (LEAN) epilogue_lean<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane, pre);
+        if constexpr (LEAN == 1) epilogue_lean<FM, FN, WM, WN>(p, acc, m0, n0, wm, wn, lane, pre);
         else epilogue<FM, FN, WM, WN, true>(p, acc, m0, n0, wm, wn, lane, &pre);
     }
     if constexpr (STAMP) {
@@ -525,11 +583,11 @@ constexpr bool has_lean() { return MODE == 0 && !STAMP && BM * BN / (NW * 64) <=
 
 template <int BM, int BN, int ST, int MODE, int NW, bool PF = false, bool STAMP = false, bool ALT = false>
 hipError_t ring_attr() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds<BM, BN, ST, NW>());
     if constexpr (has_lean<BM, BN, MODE, NW, STAMP>()) {
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, true>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, ring_lds<BM, BN, ST, NW>());
     }
     return e;
@@ -542,12 +600,24 @@ void launch_ring(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
         // a plain Linear (optional bias, optional residual, f16 out): the kernel with the lean epilogue
         if (a.epi_prefetch && a.splitk <= 1 && !a.rowbias && a.act == FIE_ACT_NONE && a.scale == 1.f && !a.gn_partial && !a.out_f8 && !a.w_scale && !a.oscat &&
             a.probe == 0) {
-            fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, true>), grid, dim3(NW * 64), lds, a);
+            fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, 1>), grid, dim3(NW * 64), lds, a);
             return;
         }
     }
-    fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, false>), grid, dim3(NW * 64), lds, a);
+    fie_launch(ctx, (gemm3_kernel<BM, BN, ST, MODE, NW, PF, STAMP, ALT, 0>), grid, dim3(NW * 64), lds, a);
 }
+
+// LayerNorm folded into the GEMM (GemmArgs::ln_tab, LEAN == 2): built for the four tiles the transformer blocks' LN consumers run on
+template <int BM, int BN, int ST, int NW, bool PF = false, bool ALT = false>
+void launch_ring_ln(fie_ctx* ctx, const GemmArgs& a, dim3 grid) {
+    fie_launch(ctx, (gemm3_kernel<BM, BN, ST, 0, NW, PF, false, ALT, 2>), grid, dim3(NW * 64), (ring_lds<BM, BN, ST, NW>()), a);
+}
+template <int BM, int BN, int ST, int NW, bool PF = false, bool ALT = false>
+hipError_t ring_attr_ln() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, 0, NW, PF, false, ALT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               ring_lds<BM, BN, ST, NW>());
+}
+constexpr bool is_ln_code(int code) { return code == 42 || code == 48 || code == 96 || code == 64; }
 
 // ---- tile codes (also the values fie_debug_force_tile / fie_debug_tile_override take)
 //   1 / 2 / 3      gemm_kernel   128x128 / 128x64 / 64x64 (any shape)
@@ -697,7 +767,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
         FIE_DESC(ctx, "conv M=%d N=%d K=%d in=%dx%dx%d s%d u%d%s%s code=%d flop=%.0f", a.M * (a.oscat == 2 ? 4 : 1), a.N, a.K, a.H, a.W, a.Cin, a.stride, a.ups,
                  a.taps2 ? " up2x-parity" : "", a.A2 ? " +1x1" : "", code + 10000 * (split > 1 ? split : 0), 2.0 * a.M * a.N * a.K * (a.oscat == 2 ? 4 : 1));
     else
-        FIE_DESC(ctx, "gemm M=%d N=%d K=%d act=%d%s%s code=%d flop=%.0f", a.M, a.N, a.K, a.act, a.res ? " +res" : "", a.w_scale ? (a.a_scale != 0.f ? " a8w8" : " w8") : "", code + 10000 * (split > 1 ? split : 0), 2.0 * a.M * a.N * a.K);
+        FIE_DESC(ctx, "gemm M=%d N=%d K=%d act=%d%s%s%s code=%d flop=%.0f", a.M, a.N, a.K, a.act, a.res ? " +res" : "", a.ln_tab ? " +ln" : "", a.w_scale ? (a.a_scale != 0.f ? " a8w8" : " w8") : "", code + 10000 * (split > 1 ? split : 0), 2.0 * a.M * a.N * a.K);
     if (x8) {
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "gemm3x8_kernel<%dx%d> (gemm, fp8 activations x fp8 weights, tile code %d%s", t->bm, t->bn, code, split > 1 ? "" : ")");
         if (split > 1) snprintf(ctx->last_kernel + strlen(ctx->last_kernel), 24, ", split-K %d)", split);
@@ -709,6 +779,18 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     }
     const dim3 grid((unsigned)(a.nbm * a.nbn * (a.oscat == 2 ? 4 : 1) * split)), block(256);
     constexpr int M3 = MODE == 1 ? 2 : 0;
+    if (a.ln_tab) {
+        FIE_REQUIRE(MODE == 0 && is_ln_code(code) && split == 1, "LayerNorm-folded GEMM: tile code %d not built for it", code);
+        FIE_REQUIRE((code == 64) == (a.act == FIE_ACT_GEGLU), "LayerNorm-folded GEMM: GEGLU runs on tile 64 and nothing else does (code %d, act %d)", code, a.act);
+        switch (code) {
+            case 42: launch_ring_ln<128, 64, 3, 4>(ctx, a, grid); break;
+            case 48: launch_ring_ln<128, 80, 3, 4>(ctx, a, grid); break;
+            case 96: launch_ring_ln<256, 128, 3, 8, true>(ctx, a, grid); break;
+            case 64: launch_ring_ln<256, 320, 2, 8, false, true>(ctx, a, grid); break;
+        }
+        FIE_LAUNCH_CHECK();
+        return FIE_OK;
+    }
     switch (code) {
         case 1: fie_launch(ctx, (gemm_kernel<128, 128, MODE>), grid, block, 0, a); break;
         case 2: fie_launch(ctx, (gemm_kernel<128, 64, MODE>), grid, block, 0, a); break;
@@ -867,6 +949,19 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
         FIE_REQUIRE(dma_ok && fie_conv_halo_gna_ok(a), "fie_conv3x3_gn_nhwc_f16: shape / epilogue not built for the fused form (ask fie_conv3x3_gn_ok first)");
         return run_code<MODE>(ctx, a, 72, -1, dma_ok, 1);
     }
+    if (MODE == 0 && a.ln_tab) {
+        // LayerNorm folded in: four tiles, chosen by rule (no tuner: the choice among them does not change the sums, every one adds K in the same order)
+        FIE_REQUIRE(dma_ok, "fie_gemm_ln_f16: operands too large for the LDS-DMA kernels");
+        auto blocks = [&](int bm, int bn) { return (int64_t)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+        int code;
+        if (a.act == FIE_ACT_GEGLU) code = 64;
+        else if (a.N % 128 == 0 && blocks(256, 128) >= 150 && (a.N >= 1536 || a.M >= 16384)) code = 96;
+        else if (a.N % 80 == 0 && blocks(128, 80) > ctx->num_cus && blocks(128, 80) <= 2 * ctx->num_cus) code = 48;      // where the tuner takes 48 for the plain projection (M 8192 x N 640)
+        else code = 42;
+        const int forced = ctx->force_tile % 1000;
+        if (forced && is_ln_code(forced) && (forced == 64) == (a.act == FIE_ACT_GEGLU) && (forced != 48 || a.N % 80 == 0)) code = forced;
+        return run_code<MODE>(ctx, a, code, -1, dma_ok, 1);
+    }
     int code = heuristic_code<MODE>(ctx, a, dma_ok);
     int order = -1;                // 0: n-tiles fastest (an XCD owns a range of activation rows), 1: m-tiles fastest; -1: estimate
     int split = 1;                 // encoded choices: split-K factor * 10000 + (1000 / 2000: forced tile order) + tile code
@@ -957,6 +1052,10 @@ hipError_t ring_attrs() {
 int fie_gemm_init(void) {
     hipError_t e = ring_attrs<0>();
     if (e == hipSuccess) e = ring_attrs<2>();
+    if (e == hipSuccess) e = ring_attr_ln<128, 64, 3, 4>();
+    if (e == hipSuccess) e = ring_attr_ln<128, 80, 3, 4>();
+    if (e == hipSuccess) e = ring_attr_ln<256, 128, 3, 8, true>();
+    if (e == hipSuccess) e = ring_attr_ln<256, 320, 2, 8, false, true>();
     if (e != hipSuccess) {
         fie_set_error("gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         return FIE_EHIP;
@@ -1146,6 +1245,27 @@ int fie_gemm_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void*
                  float scale, int act) {
     return gemm_impl("fie_gemm_f16", ctx, A1, lda1, K1, A2, lda2, Wpacked, ldw, nullptr, C, ldc, M, N, K, bias, rowbias, ld_rowbias,
                      rows_per_batch, residual, ldr, scale, act);
+}
+
+int fie_gemm_ln_f16(fie_ctx* ctx, const void* X, int64_t ldx, const void* Wfolded, int64_t ldw, const float* ln_tab, float eps, void* C, int64_t ldc,
+                    int M, int N, int K, int act) {
+    const GnTarget gn = grab_gn_target(ctx);
+    (void)gn;
+    FIE_REQUIRE(ctx && X && Wfolded && ln_tab && C, "fie_gemm_ln_f16: NULL ctx/X/W/ln_tab/C");
+    FIE_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0, "fie_gemm_ln_f16: bad shape M=%d N=%d K=%d (K must be a multiple of 64)", M, N, K);
+    FIE_REQUIRE(ldx % 8 == 0 && ldx >= K, "fie_gemm_ln_f16: ldx=%lld invalid", (long long)ldx);
+    FIE_REQUIRE(ldw % BK == 0 && ldw >= K, "fie_gemm_ln_f16: ldw=%lld must be a multiple of 64 covering K", (long long)ldw);
+    FIE_REQUIRE(act == FIE_ACT_NONE || (act == FIE_ACT_GEGLU && N % 320 == 0), "fie_gemm_ln_f16: act %d (none, or GEGLU with N %% 320 == 0)", act);
+    FIE_REQUIRE(eps > 0.f, "fie_gemm_ln_f16: eps must be positive");
+    if (int e = check_epilogue("fie_gemm_ln_f16", N, ldc, nullptr, 0, act)) return e;
+    GemmArgs a = {};
+    a.A1 = (const half_t*)X; a.lda1 = ldx; a.K1 = K;
+    a.Wt = (const half_t*)Wfolded; a.ldw = ldw; a.C = (half_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.rows_per_batch = 1; a.scale = 1.f; a.act = act;
+    a.a1_bytes = ((int64_t)(M - 1) * ldx + K) * 2;
+    a.w_bytes = fie_roundup(N, 128) * ldw * 2;
+    a.ln_tab = ln_tab; a.ln_eps = eps;
+    return launch<0>(ctx, a);
 }
 
 int fie_gemm_w8_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void* A2, int64_t lda2, const void* W8packed,

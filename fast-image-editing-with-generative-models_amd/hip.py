@@ -52,6 +52,7 @@ SIGNATURES = {
     "fie_vae_decode": [_P],
     "fie_clip_text_forward": [_P],
     "fie_gemm_f16": [_P, _P, _L, _I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _L, _I, _P, _L, _F, _I],
+    "fie_gemm_ln_f16": [_P, _P, _L, _P, _L, _P, _F, _P, _L, _I, _I, _I, _I],
     "fie_conv3x3_nhwc_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _L, _I, _P, _P, _L, _P, _L, _F, _I],
     "fie_pack_rows_f8": [_P, _P, _L, _I, _I, _P, _L, _I, _P, _I],
     "fie_pack_conv3x3_f8": [_P, _P, _I, _I, _I, _P, _L, _I, _P],
@@ -276,6 +277,8 @@ class Context:
         self.gn_quads = os.environ.get("FIE_GN_QUADS", "1") != "0"      # ... also for the UNet's 20 / 40-channel groups (quad partials); A/B switch
         self._epi_prefetch = True                 # C side default (fie_debug_epilogue_prefetch)
         self.up2x_parity = os.environ.get("FIE_UP2X_PARITY", "1") != "0"
+        # transformer blocks: LayerNorm folded into the projection that consumes it (fie_gemm_ln_f16: no LayerNorm launch, no normalised tensor); A/B switch
+        self.ln_fold = os.environ.get("FIE_LN_FOLD", "1") != "0"
         self.conv_plus_shortcut = os.environ.get("FIE_CONV_PLUS", "1") != "0"   # resnet conv2 + 1x1 shortcut as one GEMM (fie_conv3x3_plus_nhwc_f16)      # 2x-upsampling convs as four 2x2 convs (fie_conv_up2x_nhwc_f16)
         self._resize_tables = {}       # (in, out) -> (taps, bounds, ksize) of the LANCZOS resample, on the device
         self.ws_tag = 0
@@ -592,6 +595,34 @@ class Context:
                                 rowbias.stride(0) if rowbias is not None else 0, rows_per_batch, _p(residual),
                                 residual.stride(0) if residual is not None else 0, float(scale), act))
         out._gn_tag = tag
+        return out
+
+    def fold_layernorm(self, w, bias, gamma, beta, geglu=False):
+        """Prepares a Linear whose input is a LayerNorm for gemm_ln (include/fie.h: fie_gemm_ln_f16): the packed f16 matrix of W * gamma and the fp32 table
+        [(sum_k Wf[n, k], (W beta)[n] + bias[n])] in the packed column order.  The column sums run over the ROUNDED folded weights, so that
+        x Wf^T - mean * colsum is exactly (x - mean) Wf^T."""
+        w = w.to(self.device, torch.float32)
+        n, k = w.shape
+        wf = (w * gamma.to(self.device, torch.float32)[None, :]).to(torch.float16)
+        s = wf.float().sum(1)
+        b = w @ beta.to(self.device, torch.float32)
+        if bias is not None:
+            b = b + bias.to(self.device, torch.float32)
+        tab = torch.stack([s, b], 1)
+        if geglu:
+            tab = torch.stack([tab[: n // 2], tab[n // 2:]], 1).reshape(n, 2)
+        return self.pack_linear(wf, geglu=geglu, quant=False), tab.contiguous()
+
+    def gemm_ln(self, x, wp, n, tab, eps=1e-5, act=ACT_NONE, out=None):
+        """out = act(LayerNorm(x) @ W^T + bias) with the LayerNorm folded into the GEMM (fold_layernorm prepared wp / tab); x: [M, K] un-normalised."""
+        self.sync_stream()
+        m, k = x.shape
+        nout = n // 2 if act == ACT_GEGLU else n
+        if out is None:
+            out = self._alloc((m, nout))
+        assert x.stride(1) == 1 and out.stride(1) == 1 and tab.dtype == torch.float32 and tab.shape == (n, 2) and not self.f32
+        _chk(lib().fie_gemm_ln_f16(self.h, _p(x), x.stride(0), _p(wp), wp.stride(0), _p(tab), float(eps), _p(out), out.stride(0), m, n, k, act))
+        out._gn_tag = None
         return out
 
     def conv3x3_plus(self, x, wp, cout, x2, x3=None, bias=None, rowbias=None, scale=1.0, act=ACT_NONE, gn_groups=None):

@@ -168,6 +168,15 @@ class TBlock:
         self.ff1 = Linear(ctx, sd, p + "ff.net.0.proj", geglu=True)
         self.ff2 = Linear(ctx, sd, p + "ff.net.2")
         self.kv_cache = None
+        # LayerNorm folded into its consumer (include/fie.h: fie_gemm_ln_f16): norm1 -> qkv, norm2 -> to_q, norm3 -> GEGLU projection read the UN-normalised
+        # stream; (W * gamma, column sums, W beta + bias) prepared here.  f16 weights only (the fp8 configuration's LayerNorm writes e4m3), K % 64 == 0,
+        # GEGLU on the 256x320 tile (N = 8 c % 320 == 0).  ctx.ln_fold (FIE_LN_FOLD=0) is the A/B switch: the unfolded matrices stay loaded
+        self.folded = None
+        if (not ctx.f32 and not ctx.w8 and c % 64 == 0 and (8 * c) % 320 == 0 and all(torch.is_tensor(l.wp) for l in (self.qkv, self.q2, self.ff1))):
+            ln = [(sd[p + f"norm{i}.weight"], sd[p + f"norm{i}.bias"]) for i in (1, 2, 3)]
+            self.folded = (ctx.fold_layernorm(wqkv, None, *ln[0]),
+                           ctx.fold_layernorm(sd[p + "attn2.to_q.weight"], sd.get(p + "attn2.to_q.bias"), *ln[1]),
+                           ctx.fold_layernorm(sd[p + "ff.net.0.proj.weight"], sd.get(p + "ff.net.0.proj.bias"), *ln[2], geglu=True))
         # BASELINE config 5: every projection whose input is produced by LayerNorm / attention / the GEGLU epilogue reads e4m3 activations
         self.a8 = all(l.a8 for l in (self.qkv, self.o1, self.q2, self.o2, self.ff1, self.ff2)) and head_dim == 64
         # dequantisation scales of the six e4m3 tensors of the block (LN1, attention 1, LN2, attention 2, LN3, GEGLU output): value = byte * s8[i].
@@ -200,6 +209,19 @@ class TBlock:
             return self._call_a8(ctx, h, text, batch, tokens, text_len)
         rec = (lambda t, i: ctx.amax_into(t, am[i:i + 1])) if am is not None else (lambda t, i: None)
         c = self.c
+        if self.folded is not None and ctx.ln_fold and am is None:
+            (wq, tq), (w2, t2), (wf, tf) = self.folded
+            qkv = ctx.gemm_ln(h, wq, 3 * c, tq)
+            a = ctx.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], self.heads, self.hd, tokens, tokens, batch)
+            h = self.o1(ctx, a, residual=h)
+            q = ctx.gemm_ln(h, w2, c, t2)
+            if self.kv_cache is None:
+                self.kv_cache = self.kv2(ctx, text)
+            kv = self.kv_cache
+            a = ctx.attention(q, kv[:, :c], kv[:, c:], self.heads, self.hd, tokens, text_len, batch)
+            h = self.o2(ctx, a, residual=h)
+            f = ctx.gemm_ln(h, wf, 8 * c, tf, act=hip.ACT_GEGLU)
+            return self.ff2(ctx, f, residual=h)
         y = ctx.layernorm(h, self.ln[0].g, self.ln[0].b)
         rec(y, 0)
         qkv = self.qkv(ctx, y)

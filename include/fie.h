@@ -200,6 +200,18 @@ int fie_gemm_f16(fie_ctx* ctx, const void* A1, int64_t lda1, int K1, const void*
                  const void* bias, const void* rowbias, int64_t ld_rowbias, int rows_per_batch,
                  const void* residual, int64_t ldr, float scale, int act);
 
+/* ---- LayerNorm folded into its consumer GEMM.  Replaces the pair nn.LayerNorm -> nn.Linear of upstream diffusers models/attention.py
+ * BasicTransformerBlock (norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q, norm3 -> ff.net.0.proj), reached from src/pipeline.py:261.
+ *   C[m, n] = act( sum_k LN(X)[m, k] * W[n, k] + bias[n] ),  LN(x) = (x - mean) * rsqrt(var + eps) * gamma + beta over the K columns of row m
+ * computed WITHOUT ever forming LN(X):  = rstd[m] * (sum_k X[m, k] * Wf[n, k] - mean[m] * ln_tab[n][0]) + ln_tab[n][1]  with
+ *   Wfolded = pack(W * gamma) (f16, the packed layout of fie_gemm_f16),  ln_tab[n] = (sum_k Wfolded[n, k], sum_k W[n, k] * beta[k] + bias[n]) in fp32,
+ * in the PACKED column order (GEGLU: value / gate interleaved as fie_pack_rows_f16 with interleave2).  The row statistics are summed (fp32) from the
+ * activation fragments on their way to the MFMAs; var = E[x^2] - mean^2, clamped at 0.  X: [M, K] f16 un-normalised (ldx elements), K % 64 == 0;
+ * act = FIE_ACT_NONE or FIE_ACT_GEGLU (N % 320 == 0: the 256x320 tile; output has N/2 columns).  Differences from the two-launch sequence: the
+ * normalised activation is not rounded to f16, W * gamma is (once, at load). */
+int fie_gemm_ln_f16(fie_ctx* ctx, const void* X, int64_t ldx, const void* Wfolded, int64_t ldw, const float* ln_tab, float eps, void* C, int64_t ldc,
+                    int M, int N, int K, int act);
+
 /* ---- K1 3x3 convolution, NHWC, implicit GEMM on fp16 MFMA.  Replaces torch Conv2d(3x3) dispatched by upstream
  * resnet.py / downsampling.py / upsampling.py / vae.py / controlnet.py conditioning embedding.
  *   X: [B, H, W, Cin] f16 (Cin % 8 == 0).  If upsample2x != 0 the conv sees nearest-2x upsampled X (never stored).

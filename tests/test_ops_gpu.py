@@ -209,6 +209,37 @@ def test_layernorm(fie, rows, c):
     assert rel_err(out, ref) < 3e-3
 
 
+@pytest.mark.parametrize("m,n,k,geglu,tile", [(2048, 3840, 1280, False, 96), (2048, 1280, 1280, False, 42), (8192, 640, 640, False, 48),
+                                             (2048, 10240, 1280, True, 64), (1000, 640, 640, False, 42), (154, 1280, 1280, False, 42),
+                                             (300, 2560, 320, True, 64), (2048, 1280, 1280, False, 48), (8192, 1920, 640, False, 42)])
+def test_gemm_with_layernorm_folded_in(fie, m, n, k, geglu, tile):
+    """fie_gemm_ln_f16 (LayerNorm folded into the consumer GEMM: statistics from the activation fragments, rstd * (acc - mean * colsum) + b' in the epilogue)
+    against LayerNorm -> Linear (-> GEGLU) in fp32 on the same f16 inputs, on each of the four tiles it is built for; rows with a large common offset
+    (mean ~ 3 sigma) so the mean correction carries weight; ragged M.  Also against the two-launch HIP sequence."""
+    from fie_amd import hip
+    x = (rnd(m, k, seed=1) * 2 + rnd(m, 1, seed=7) * 6)
+    w, b = rnd(n, k, seed=2) / math.sqrt(k), rnd(n, seed=3) * 0.1
+    g, bta = 1 + 0.2 * rnd(k, seed=4), 0.1 * rnd(k, seed=5)
+    y = F.layer_norm(x.float(), (k,), g.float(), bta.float(), 1e-5) @ w.float().t() + b.float()
+    ref = y[:, : n // 2] * F.gelu(y[:, n // 2:]) if geglu else y
+    wp, tab = fie.fold_layernorm(w, b, g, bta, geglu=geglu)
+    act = hip.ACT_GEGLU if geglu else hip.ACT_NONE
+    fie.force_tile(tile)
+    try:
+        out = fie.gemm_ln(x.to(DEV), wp, n, tab, act=act)
+        kern = hip.last_gemm_kernel(fie)
+    finally:
+        fie.force_tile(0)
+    assert f"tile code {tile}" in kern, kern
+    two = fie.gemm(fie.layernorm(x.to(DEV), g.to(DEV), bta.to(DEV)), fie.pack_linear(w, geglu=geglu), n, act=act,
+                   bias=(torch.stack([b[: n // 2], b[n // 2:]], 1).reshape(-1) if geglu else b).to(DEV))
+    e_fold, e_two = rel_err(out, ref), rel_err(two, ref)
+    print(f"LN fold M={m} N={n} K={k} tile {tile}: folded {e_fold:.2e}, LayerNorm + GEMM {e_two:.2e} (vs fp32)")
+    assert e_fold < 3e-3 and e_fold < 2 * e_two + 1e-4
+    # whichever tile the rule takes adds K (and the row sums) in the same order as the forced one: bit-equal
+    assert torch.equal(out, fie.gemm_ln(x.to(DEV), wp, n, tab, act=act))
+
+
 def test_sinusoid_known_answers(fie):
     # SURVEY A.1 KAT: t = 499, dim 320
     out = torch.zeros(1, 320, device=DEV, dtype=torch.float16)

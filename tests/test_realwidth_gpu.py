@@ -59,6 +59,17 @@ def test_basic_transformer_block_real_width(fie, tokens, c):
     with torch.no_grad():
         ref = nets.basic_transformer_block(sd32, p, x.float(), text.float(), c // 64)
     assert rel_err(out.view(2, tokens, c), ref) < 1e-2
+    # the three LayerNorms ran folded into their consumer GEMMs (fie_gemm_ln_f16); the same block with LayerNorm launches (ctx.ln_fold off: A/B switch)
+    assert blk.folded is not None and fie.ln_fold
+    fie.ln_fold = False
+    try:
+        blk.kv_cache = None
+        two = blk(fie, x.view(2 * tokens, c).cuda(), text.view(2 * 77, 2048).cuda(), 2, tokens, 77)
+    finally:
+        fie.ln_fold = True
+    e_fold, e_two = rel_err(out.view(2, tokens, c), ref), rel_err(two.view(2, tokens, c), ref)
+    print(f"transformer block {tokens} x {c}: LayerNorm folded {e_fold:.2e}, LayerNorm launches {e_two:.2e} (vs the fp32 oracle)")
+    assert e_two < 1e-2 and rel_err(out, two) < 5e-3
 
 
 def test_resnet_1280_at_32x32_with_2560_channel_concat(fie):
