@@ -179,8 +179,9 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     constexpr bool LNF = LEAN == 2;
     static_assert(!LNF || (MODE == 0 && !STAMP), "LayerNorm fold: GEMM view only");
     static_assert(!ALT || (NW == 8 && MODE == 0 && !PF && !STAMP), "ALT: 8-wave GEMM-view tiles without the fragment prefetch");
-    // waves as 2 (rows) x NW/2 (columns) wherever that leaves whole 16-column fragments; otherwise (128x80) all NW waves stacked along the rows
-    constexpr int WGN = (BN / (NW / 2)) % 16 == 0 ? NW / 2 : 1, WGM = NW / WGN;
+    // waves as 2 (rows) x NW/2 (columns) wherever that leaves whole 16-column fragments; otherwise (128x80) all NW waves stacked along the rows.
+    // LayerNorm fold (small tiles): stacked along the rows too -- every activation row then belongs to ONE wave, which takes its statistics (ln_take below)
+    constexpr int WGN = (LEAN == 2 && BM * BN / (NW * 256) <= 16 && (BM / NW) % 16 == 0) ? 1 : (BN / (NW / 2)) % 16 == 0 ? NW / 2 : 1, WGM = NW / WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int FM = WM / 16, FN = WN / 16;
     constexpr int NPW = BN / 8;                            // weight pieces (8 rows x 128 B) per K-step
@@ -347,13 +348,15 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     LnTab<(LNF && FM * FN <= 16) ? FN : 1> ln_pre;
     if constexpr (FM * FN <= 16) {
         if constexpr (LNF) {
-#pragma unroll
-            for (int i = 0; i < FN; ++i) ln_tab_load(p, n0 + wn * WN + i * 16 + (lane >> 4) * 4, ln_pre.lo[i], ln_pre.hi[i]);
+            // the (colsum, bias') table is loaded AFTER the K loop (below), not here with the other epilogue operands: see the note there
         } else if (LEAN || (nsplit == 1 && p.epi_prefetch)) epilogue_prefetch<FM, FN, WM, WN>(p, pre, m0, n0, wm, wn, lane);
     }
-    // LNF: the WGN waves that read the same activation fragments share the statistics work: wave column wn sums row fragments j with j % WGN == wn
-    static_assert(!LNF || FM % WGN == 0, "row fragments are dealt to the wave columns");
-    constexpr int LJ = LNF ? FM / WGN : 1;
+    // LNF: every wave sums the rows of ITS OWN activation fragments, all of them, straight-line: v_dot2c (x . 1, x . x), 8 per fragment and half K-step.
+    // (Round 4, profiles/r04_ln_fold_row_sum_variants.log: dealing the fragments to the wave columns that share them -- a wave-uniform `if` per fragment
+    // inside the K loop -- cost 5-8 us per launch whatever did the sums, VALU or two extra MFMAs per fragment (Gram diagonal + ones row): the branches
+    // split the K loop into basic blocks and every block boundary drains the LDS / MFMA pipeline.  Hence the row-stacked wave layout above: each row
+    // fragment belongs to exactly one wave, nothing is summed twice and nothing is traded through LDS.)
+    constexpr int LJ = LNF ? FM : 1;
     float ln_s[LJ], ln_q[LJ];
 #pragma unroll
     for (int t = 0; t < LJ; ++t) ln_s[t] = ln_q[t] = 0.f;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
         if constexpr (LNF) {
             static_for([&](auto jc) {
                 constexpr int j = decltype(j0c)::value + decltype(jc)::value;
-                if (WGN == 1 || j % WGN == wn) ln_dot(fa[decltype(jc)::value], ln_s[j / WGN], ln_q[j / WGN]);
+                ln_dot(fa[decltype(jc)::value], ln_s[j], ln_q[j]);
             }, std::make_integer_sequence<int, decltype(cntc)::value>{});
         }
     };
@@ -513,28 +516,26 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     }
     stamp(11);                                             // last MFMA group issued
     float ln_mean[LNF ? FM : 1], ln_rstd[LNF ? FM : 1];
+    if constexpr (LNF && FM * FN <= 16) {
+        // Loaded here, behind the K loop.  Prefetched ahead of the ring like the lean epilogue's bias / residual (40 VGPRs live across the loop), the 128x80
+        // instantiation produced wrong outputs on a loaded chip: in 16-row x 1-column spots the `- mean * colsum` term was missing -- the colsum of a
+        // lane's first column read as 0 in lanes 48..63, second row fragment only -- in 29 of 30 launches at M 8192, never at M 256, never on the other
+        // tiles; not cured by a barrier behind the loop, by 8-byte loads, by draining the table loads before the first LDS-DMA or by v_fma_mix instead
+        // of v_dot2c; gone with the statistics removed or with this placement (0 of 30 x 7 shapes differ).  Evidence: profiles/r04_ln_fold_tile48_anomaly.md
+#pragma unroll
+        for (int i = 0; i < FN; ++i) ln_tab_load(p, n0 + wn * WN + i * 16 + (lane >> 4) * 4, ln_pre.lo[i], ln_pre.hi[i]);
+    }
     if constexpr (LNF) {
-        // a lane holds the sums over its own k-slices (fq): total over the four fq lane rows, then the wave columns trade their row fragments
-        // through LDS (the ring is drained once every wave is past its last fragment read)
-#pragma unroll
-        for (int t = 0; t < LJ; ++t) {
-            ln_s[t] += __shfl_xor(ln_s[t], 16); ln_s[t] += __shfl_xor(ln_s[t], 32);
-            ln_q[t] += __shfl_xor(ln_q[t], 16); ln_q[t] += __shfl_xor(ln_q[t], 32);
-        }
-        __syncthreads();
-        float2* st = reinterpret_cast<float2*>(smem);
-        if (lane < 16) {
-#pragma unroll
-            for (int t = 0; t < LJ; ++t) st[wm * WM + (t * WGN + wn) * 16 + lane] = make_float2(ln_s[t], ln_q[t]);
-        }
-        __syncthreads();
+        // a lane holds the sums over its own k-slices (fq) of row fr, the row it owns in the epilogue: total over the four fq lane rows
         const float inv_k = 1.f / (float)p.K;
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
-            const float2 v = st[wm * WM + j * 16 + (lane & 15)];
-            const float mu = v.x * inv_k;
+            float sx = ln_s[j], sq = ln_q[j];
+            sx += __shfl_xor(sx, 16); sx += __shfl_xor(sx, 32);
+            sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+            const float mu = sx * inv_k;
             ln_mean[j] = mu;
-            ln_rstd[j] = rsqrtf(fmaxf(v.y * inv_k - mu * mu, 0.f) + p.ln_eps);
+            ln_rstd[j] = rsqrtf(fmaxf(sq * inv_k - mu * mu, 0.f) + p.ln_eps);
         }
     }
     if constexpr (FM * FN <= 16 && !LEAN) {                // split-K: only the block that draws the tile's last ticket goes on, with the summed slices
