@@ -360,13 +360,24 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     float ln_s[LJ], ln_q[LJ];
 #pragma unroll
     for (int t = 0; t < LJ; ++t) ln_s[t] = ln_q[t] = 0.f;
-    // fragments fa[0 .. CNT) are row fragments J0 .. J0 + CNT of the wave tile
-    auto ln_take = [&](auto j0c, auto cntc, const f16x8* fa) {
+    // The sums ride BETWEEN the MFMAs, a few per MFMA (issued behind the whole MFMA block they simply add their issue time: +11 us on the FF1 tile):
+    // a fragment is four register pairs = four units of two v_dot2c; ln_slice<I, NI, J0, CNT>(fa) issues the units of fragments fa[0 .. CNT) (row fragments
+    // J0 ..) that fall to column iteration I of NI
+    auto ln_unit = [&](auto jc, auto tc, const f16x8& f) {
+        constexpr int j = decltype(jc)::value, t = decltype(tc)::value;
+        const f16x2 one = {(half_t)1.f, (half_t)1.f};
+        const f16x2 v = {f[2 * t], f[2 * t + 1]};
+        ln_s[j] = __builtin_amdgcn_fdot2(v, one, ln_s[j], false);
+        ln_q[j] = __builtin_amdgcn_fdot2(v, v, ln_q[j], false);
+    };
+    auto ln_slice = [&](auto ic, auto nic, auto j0c, auto cntc, const f16x8* fa) {
         if constexpr (LNF) {
-            static_for([&](auto jc) {
-                constexpr int j = decltype(j0c)::value + decltype(jc)::value;
-                ln_dot(fa[decltype(jc)::value], ln_s[j], ln_q[j]);
-            }, std::make_integer_sequence<int, decltype(cntc)::value>{});
+            constexpr int I = decltype(ic)::value, NI = decltype(nic)::value, J0 = decltype(j0c)::value, U = 4 * decltype(cntc)::value;
+            constexpr int u0 = I * U / NI, u1 = (I + 1) * U / NI;
+            static_for([&](auto uc) {
+                constexpr int u = u0 + decltype(uc)::value;
+                ln_unit(std::integral_constant<int, J0 + u / 4>{}, std::integral_constant<int, u % 4>{}, fa[u / 4]);
+            }, std::make_integer_sequence<int, u1 - u0>{});
         }
     };
     using c0_t = std::integral_constant<int, 0>;
@@ -386,10 +397,12 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     };
     auto mfmas = [&](const f16x8* fw, const f16x8* fa) {
         if (NW == 8) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < FN; ++i)
+        static_for([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
 #pragma unroll
             for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+            ln_slice(ic, std::integral_constant<int, FN>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, FM>{}, fa);
+        }, std::make_integer_sequence<int, FN>{});
         if (NW == 8) __builtin_amdgcn_s_setprio(0);
     };
     // STAMP instances (tile codes 97 / 98, fie_debug_gemm_stamps): per-wave cycle sums of the K-loop segments, s_memtime deltas
@@ -439,7 +452,6 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
             landed(fw0, fa0);
             mfmas(fw0, fa0);
-            ln_take(c0_t{}, std::integral_constant<int, FM>{}, fa0);
             if (more && NW == 8) issue_w(kbeg + kt + ST - 1, fill);
             stage = stage + 1 == ST ? 0 : stage + 1;
             fill = fill + 1 == ST ? 0 : fill + 1;
@@ -451,7 +463,6 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
                 reads(fw0, fa0, stage, 0);
             }
             mfmas(fw1, fa1);
-            ln_take(c0_t{}, std::integral_constant<int, FM>{}, fa1);
         }
     } else
     for (int kt = 0; kt < nk; ++kt) {
@@ -493,13 +504,14 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < HM; ++j) fa[j] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * WM + (jh * HM + j) * 16 + fr, kk * 4 + fq));
                     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int i = 0; i < FN; ++i)
+                    static_for([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
 #pragma unroll
                         for (int j = 0; j < HM; ++j) acc[i][jh * HM + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][jh * HM + j], 0, 0, 0);
+                        if (jh == 0) ln_slice(ic, std::integral_constant<int, FN>{}, c0_t{}, std::integral_constant<int, HM>{}, fa);
+                        else ln_slice(ic, std::integral_constant<int, FN>{}, std::integral_constant<int, HM>{}, std::integral_constant<int, HM>{}, fa);
+                    }, std::make_integer_sequence<int, FN>{});
                     __builtin_amdgcn_s_setprio(0);
-                    if (jh == 0) ln_take(c0_t{}, std::integral_constant<int, HM>{}, fa);
-                    else ln_take(std::integral_constant<int, HM>{}, std::integral_constant<int, HM>{}, fa);
                 }
             } else {
                 f16x8 fw[FN], fa[FM];
@@ -507,7 +519,6 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
                 if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 stamp(2 + 3 * kk);                         // 2 / 5: fragment reads issued and landed
                 mfmas(fw, fa);
-                ln_take(c0_t{}, std::integral_constant<int, FM>{}, fa);
                 stamp(3 + 3 * kk);                         // 3 / 6: 16 MFMAs issued
             }
         }
@@ -517,11 +528,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
     stamp(11);                                             // last MFMA group issued
     float ln_mean[LNF ? FM : 1], ln_rstd[LNF ? FM : 1];
     if constexpr (LNF && FM * FN <= 16) {
-        // Loaded here, behind the K loop.  Prefetched ahead of the ring like the lean epilogue's bias / residual (40 VGPRs live across the loop), the 128x80
-        // instantiation produced wrong outputs on a loaded chip: in 16-row x 1-column spots the `- mean * colsum` term was missing -- the colsum of a
-        // lane's first column read as 0 in lanes 48..63, second row fragment only -- in 29 of 30 launches at M 8192, never at M 256, never on the other
-        // tiles; not cured by a barrier behind the loop, by 8-byte loads, by draining the table loads before the first LDS-DMA or by v_fma_mix instead
-        // of v_dot2c; gone with the statistics removed or with this placement (0 of 30 x 7 shapes differ).  Evidence: profiles/r04_ln_fold_tile48_anomaly.md
+        // loaded behind the K loop: 16-64 VGPRs that nothing in the loop needs
 #pragma unroll
         for (int i = 0; i < FN; ++i) ln_tab_load(p, n0 + wn * WN + i * 16 + (lane >> 4) * 4, ln_pre.lo[i], ln_pre.hi[i]);
     }
@@ -618,7 +625,9 @@ hipError_t ring_attr_ln() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, BN, ST, 0, NW, PF, false, ALT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                ring_lds<BM, BN, ST, NW>());
 }
-constexpr bool is_ln_code(int code) { return code == 42 || code == 48 || code == 96 || code == 64; }
+// (128x80, tile 48, was built too and is NOT offered: its instantiation returned wrong values in 16-row x 1-column spots on a loaded chip, in every form
+// tried, while 42 / 96 / 64 never did: profiles/r04_ln_fold_tile48_anomaly.md; tests/test_ops_gpu.py screens the three that ship)
+constexpr bool is_ln_code(int code) { return code == 42 || code == 96 || code == 64; }
 
 // ---- tile codes (also the values fie_debug_force_tile / fie_debug_tile_override take)
 //   1 / 2 / 3      gemm_kernel   128x128 / 128x64 / 64x64 (any shape)
@@ -785,7 +794,6 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
         FIE_REQUIRE((code == 64) == (a.act == FIE_ACT_GEGLU), "LayerNorm-folded GEMM: GEGLU runs on tile 64 and nothing else does (code %d, act %d)", code, a.act);
         switch (code) {
             case 42: launch_ring_ln<128, 64, 3, 4>(ctx, a, grid); break;
-            case 48: launch_ring_ln<128, 80, 3, 4>(ctx, a, grid); break;
             case 96: launch_ring_ln<256, 128, 3, 8, true>(ctx, a, grid); break;
             case 64: launch_ring_ln<256, 320, 2, 8, false, true>(ctx, a, grid); break;
         }
@@ -957,10 +965,9 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
         int code;
         if (a.act == FIE_ACT_GEGLU) code = 64;
         else if (a.N % 128 == 0 && blocks(256, 128) >= 150 && (a.N >= 1536 || a.M >= 16384)) code = 96;
-        else if (a.N % 80 == 0 && blocks(128, 80) > ctx->num_cus && blocks(128, 80) <= 2 * ctx->num_cus) code = 48;      // where the tuner takes 48 for the plain projection (M 8192 x N 640)
         else code = 42;
         const int forced = ctx->force_tile % 1000;
-        if (forced && is_ln_code(forced) && (forced == 64) == (a.act == FIE_ACT_GEGLU) && (forced != 48 || a.N % 80 == 0)) code = forced;
+        if (forced && is_ln_code(forced) && (forced == 64) == (a.act == FIE_ACT_GEGLU)) code = forced;
         return run_code<MODE>(ctx, a, code, -1, dma_ok, 1);
     }
     int code = heuristic_code<MODE>(ctx, a, dma_ok);
@@ -1054,7 +1061,6 @@ int fie_gemm_init(void) {
     hipError_t e = ring_attrs<0>();
     if (e == hipSuccess) e = ring_attrs<2>();
     if (e == hipSuccess) e = ring_attr_ln<128, 64, 3, 4>();
-    if (e == hipSuccess) e = ring_attr_ln<128, 80, 3, 4>();
     if (e == hipSuccess) e = ring_attr_ln<256, 128, 3, 8, true>();
     if (e == hipSuccess) e = ring_attr_ln<256, 320, 2, 8, false, true>();
     if (e != hipSuccess) {

@@ -220,7 +220,7 @@ class TBlock:
             kv = self.kv_cache
             a = ctx.attention(q, kv[:, :c], kv[:, c:], self.heads, self.hd, tokens, text_len, batch)
             h = self.o2(ctx, a, residual=h)
-            f = ctx.gemm_ln(h, wf, 8 * c, tf, act=hip.ACT_GEGLU)
+            f = ctx.gemm_ln(h, wf, 8 * c, tf, act=hip.ACT_GEGLU) if ctx.ln_fold_ff1 else self.ff1(ctx, ctx.layernorm(h, self.ln[2].g, self.ln[2].b))
             return self.ff2(ctx, f, residual=h)
         y = ctx.layernorm(h, self.ln[0].g, self.ln[0].b)
         rec(y, 0)

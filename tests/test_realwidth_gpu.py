@@ -65,11 +65,15 @@ def test_basic_transformer_block_real_width(fie, tokens, c):
     try:
         blk.kv_cache = None
         two = blk(fie, x.view(2 * tokens, c).cuda(), text.view(2 * 77, 2048).cuda(), 2, tokens, 77)
+        fie.ln_fold, ff1 = True, fie.ln_fold_ff1
+        fie.ln_fold_ff1 = not ff1                            # ... and norm3 -> GEGLU projection the other way round (default: LayerNorm launch)
+        blk.kv_cache = None
+        three = blk(fie, x.view(2 * tokens, c).cuda(), text.view(2 * 77, 2048).cuda(), 2, tokens, 77)
     finally:
-        fie.ln_fold = True
-    e_fold, e_two = rel_err(out.view(2, tokens, c), ref), rel_err(two.view(2, tokens, c), ref)
-    print(f"transformer block {tokens} x {c}: LayerNorm folded {e_fold:.2e}, LayerNorm launches {e_two:.2e} (vs the fp32 oracle)")
-    assert e_two < 1e-2 and rel_err(out, two) < 5e-3
+        fie.ln_fold, fie.ln_fold_ff1 = True, ff1
+    e_fold, e_two, e_three = rel_err(out.view(2, tokens, c), ref), rel_err(two.view(2, tokens, c), ref), rel_err(three.view(2, tokens, c), ref)
+    print(f"transformer block {tokens} x {c}: LayerNorm folded {e_fold:.2e}, LayerNorm launches {e_two:.2e}, FF1 fold toggled {e_three:.2e} (vs the fp32 oracle)")
+    assert e_two < 1e-2 and e_three < 1e-2 and rel_err(out, two) < 5e-3 and rel_err(out, three) < 5e-3
 
 
 def test_resnet_1280_at_32x32_with_2560_channel_concat(fie):

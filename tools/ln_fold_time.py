@@ -16,7 +16,8 @@ from tools.cold_weights import time_rot  # noqa: E402
 ctx = hip.context(0)
 ctx.autotune(True)
 tot_two = tot_fold = 0.0
-for name, m, n, k, geglu, per_edit in [("qkv", 2048, 3840, 1280, False, 112), ("to_q (cross)", 2048, 1280, 1280, False, 112), ("FF1 GEGLU", 2048, 10240, 1280, True, 112),
+for name, m, n, k, geglu, per_edit in [      # per_edit: launches per edit (SSD-1B + ControlNet, 2 evaluations); FF1 is not folded by default (FIE_LN_FOLD_FF1)
+                                       ("qkv", 2048, 3840, 1280, False, 112), ("to_q (cross)", 2048, 1280, 1280, False, 112), ("FF1 GEGLU", 2048, 10240, 1280, True, 112),
                                        ("qkv", 8192, 1920, 640, False, 24), ("to_q (cross)", 8192, 640, 640, False, 24), ("FF1 GEGLU", 8192, 5120, 640, True, 24)]:
     copies = max(2, int(600e6 / (n * k * 2)) + 1)
     x = torch.randn(m, k, device="cuda", dtype=torch.float16) * 2 + 1
