@@ -380,6 +380,12 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             }, std::make_integer_sequence<int, u1 - u0>{});
         }
     };
+    auto ln_pin = [&]() {
+        if constexpr (LNF) {
+#pragma unroll
+            for (int t = 0; t < LJ; ++t) asm volatile("" : "+v"(ln_s[t]), "+v"(ln_q[t]));
+        }
+    };
     using c0_t = std::integral_constant<int, 0>;
 
 #pragma unroll
@@ -448,6 +454,12 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             stamp(kt == 0 ? 7 : 0);                        // whole K-steps only: a stamp drains lgkmcnt
             const bool more = kt + ST - 1 < nk && p.probe != 3;
             if (more) { issue(kbeg + kt + ST - 1, fill); if (NW != 8) issue_w(kbeg + kt + ST - 1, fill); }
+            // LNF: every use of a fragment set stays on its side of the asm reads that refill it.  The row sums are plain VALU uses of fa: the scheduler
+            // sank them below the next `reads`, the old fragments then outlived the statement, the new ones got other registers and a COPY at the loop's
+            // back edge -- a v_mov of asm-loaded registers ahead of their lgkmcnt wait (cdna_hip_programming.md, "What hipcc does not do" 1): stale B
+            // operands whenever LDS was slow (round 4: a whole edit differed between replays of one graph).  ln_pin: an asm statement that takes the sums, so
+            // the v_dot2c's that feed them stand in front of it, and asm volatile statements keep their order.  Audit: no v_mov_b64 of fragments in the loop
+            ln_pin();
             reads(fw1, fa1, stage, 1);
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
             landed(fw0, fa0);
@@ -460,6 +472,7 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(GemmArgs p) {
             landed(fw1, fa1);
             if (kt + 1 < nk) {
                 wait_stage<NP, ST>(min(kt + ST - 1, nk - 1) - (kt + 1));
+                ln_pin();
                 reads(fw0, fa0, stage, 0);
             }
             mfmas(fw1, fa1);

@@ -211,10 +211,11 @@ class TBlock:
         c = self.c
         if self.folded is not None and ctx.ln_fold and am is None:
             (wq, tq), (w2, t2), (wf, tf) = self.folded
-            qkv = ctx.gemm_ln(h, wq, 3 * c, tq)
+            which = ctx.ln_fold_which
+            qkv = ctx.gemm_ln(h, wq, 3 * c, tq) if "qkv" in which else self.qkv(ctx, ctx.layernorm(h, self.ln[0].g, self.ln[0].b))
             a = ctx.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], self.heads, self.hd, tokens, tokens, batch)
             h = self.o1(ctx, a, residual=h)
-            q = ctx.gemm_ln(h, w2, c, t2)
+            q = ctx.gemm_ln(h, w2, c, t2) if "q2" in which else self.q2(ctx, ctx.layernorm(h, self.ln[1].g, self.ln[1].b))
             if self.kv_cache is None:
                 self.kv_cache = self.kv2(ctx, text)
             kv = self.kv_cache

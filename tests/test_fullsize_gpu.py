@@ -110,7 +110,8 @@ def test_full_size_determinism_graph_and_eval_count(big):
                                    generator=torch.Generator("cpu").manual_seed(42)).images[0]))
         assert big.last_stats == dict(unet_evals=2, cfg_batch=2, latent_hw=(128, 128), images=1)
     assert outs[0].shape == (1024, 1024, 3) and 5 < outs[0].std()
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    d01, d12 = int((outs[0] != outs[1]).sum()), int((outs[1] != outs[2]).sum())
+    assert d01 == 0 and d12 == 0, f"eager vs graph: {d01} differing bytes, graph vs graph: {d12}"
     for strength, evals in ((1.0, 4), (0.8, 3), (0.3, 1)):
         big(prompt="x", image=img, control_image=ctrl, strength=strength, guidance_scale=1.0,
             generator=torch.Generator("cpu").manual_seed(1))

@@ -274,8 +274,9 @@ def test_gemm_with_layernorm_folded_in_refuses_other_tiles(fie):
         assert "tile code 42" in hip.last_gemm_kernel(fie)
     finally:
         fie.force_tile(0)
+    wp, tab = fie.fold_layernorm(w[:384], b[:384], g, bta, geglu=True)
     with pytest.raises(hip.FieError):
-        fie.gemm_ln(rnd(256, 640, seed=1).to(DEV), wp, 640, tab, act=hip.ACT_GEGLU)      # GEGLU needs N % 320 == 0
+        fie.gemm_ln(rnd(256, 640, seed=1).to(DEV), wp, 384, tab, act=hip.ACT_GEGLU)      # GEGLU needs N % 320 == 0 (the 256x320 tile)
 
 
 def test_sinusoid_known_answers(fie):
