@@ -281,6 +281,7 @@ class Context:
         self.ln_fold = os.environ.get("FIE_LN_FOLD", "1") != "0"
         # ... also norm3 -> the GEGLU projection (256x320 tile): built and bit-checked, but the row sums add 11-15 us to a 49 us launch there (every wave of a
         # wave row sums the same fragments; dealing them out needs branches in the K loop, which cost as much): off, LayerNorm launch + plain FF1
+        self.kv_group = os.environ.get("FIE_KV_GROUP", "1") != "0"      # text K/V of all transformer blocks of a net as one GEMM per image (nn.py: _finish_kv); A/B switch
         self.ln_fold_which = os.environ.get("FIE_LN_FOLD_WHICH", "qkv,q2")      # which of the two folds run (A/B)
         self.ln_fold_ff1 = os.environ.get("FIE_LN_FOLD_FF1", "0") != "0"
         self.conv_plus_shortcut = os.environ.get("FIE_CONV_PLUS", "1") != "0"   # resnet conv2 + 1x1 shortcut as one GEMM (fie_conv3x3_plus_nhwc_f16)      # 2x-upsampling convs as four 2x2 convs (fie_conv_up2x_nhwc_f16)

@@ -163,7 +163,10 @@ class TBlock:
         self.qkv = Linear(ctx, None, None, w=wqkv)
         self.o1 = Linear(ctx, sd, p + "attn1.to_out.0")
         self.q2 = Linear(ctx, sd, p + "attn2.to_q")
-        self.kv2 = Linear(ctx, None, None, w=torch.cat([sd[p + "attn2.to_k.weight"], sd[p + "attn2.to_v.weight"]], 0))
+        self._kv_raw = torch.cat([sd[p + "attn2.to_k.weight"], sd[p + "attn2.to_v.weight"]], 0)
+        self.kv2 = Linear(ctx, None, None, w=self._kv_raw)
+        # the net's grouped text K/V projection (_CondNet._finish_kv): this block's columns of the one [2 x 77, sum 2c] result; None: the block projects its own
+        self.kv_net, self.kv_slot = None, None
         self.o2 = Linear(ctx, sd, p + "attn2.to_out.0")
         self.ff1 = Linear(ctx, sd, p + "ff.net.0.proj", geglu=True)
         self.ff2 = Linear(ctx, sd, p + "ff.net.2")
@@ -183,6 +186,20 @@ class TBlock:
         # 1 until HipImg2ImgPipeline.calibrate_fp8 measured them (powers of two: exact both ways); amax: the calibration pass's device floats
         self.s8, self.amax = [1.0] * 6, None
 
+    def _text_kv(self, ctx, text):
+        """Cross-attention K | V of the text, [B * 77, 2 c]: invariant over the denoising steps of one image, so computed once per image -- and for ALL blocks
+        of the net in ONE GEMM (M = B * 77 rows against the concatenated to_k / to_v matrices: one pass over the weights at HBM rate instead of 20-36 launches
+        of 16 us at 0.04 of the MFMA peak); a block takes its column range of the result."""
+        if self.kv_cache is None:
+            net = self.kv_net
+            if net is not None and ctx.kv_group and not ctx.calib:
+                if net._kv_out is None:
+                    net._kv_out = net.kv_all(ctx, text)
+                self.kv_cache = net._kv_out[:, self.kv_slot[0]:self.kv_slot[1]]
+            else:
+                self.kv_cache = self.kv2(ctx, text)
+        return self.kv_cache
+
     def _call_a8(self, ctx, h, text, batch, tokens, text_len):
         """The block with fp8 activations: LayerNorm, attention and the GEGLU epilogue WRITE e4m3 (value / s8[i], saturating RNE; s8 = 1 gives the
         values the fp8-weight kernels of round 2 converted per fragment), the six projections run the block-scaled fp8 MFMA with a_scale = s8[i]
@@ -194,9 +211,7 @@ class TBlock:
         h = self.o1(ctx, a, residual=h, a_scale=s[1])
         y = ctx.layernorm(h, self.ln[1].g, self.ln[1].b, out_f8=True, out_inv_scale=1.0 / s[2])
         q = self.q2(ctx, y, a_scale=s[2])
-        if self.kv_cache is None:
-            self.kv_cache = self.kv2(ctx, text)
-        kv = self.kv_cache
+        kv = self._text_kv(ctx, text)
         a = ctx.attention(q, kv[:, :c], kv[:, c:], self.heads, self.hd, tokens, text_len, batch, out_f8=True, out_inv_scale=1.0 / s[3])
         h = self.o2(ctx, a, residual=h, a_scale=s[3])
         y = ctx.layernorm(h, self.ln[2].g, self.ln[2].b, out_f8=True, out_inv_scale=1.0 / s[4])
@@ -216,9 +231,7 @@ class TBlock:
             a = ctx.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], self.heads, self.hd, tokens, tokens, batch)
             h = self.o1(ctx, a, residual=h)
             q = ctx.gemm_ln(h, w2, c, t2) if "q2" in which else self.q2(ctx, ctx.layernorm(h, self.ln[1].g, self.ln[1].b))
-            if self.kv_cache is None:
-                self.kv_cache = self.kv2(ctx, text)
-            kv = self.kv_cache
+            kv = self._text_kv(ctx, text)
             a = ctx.attention(q, kv[:, :c], kv[:, c:], self.heads, self.hd, tokens, text_len, batch)
             h = self.o2(ctx, a, residual=h)
             f = ctx.gemm_ln(h, wf, 8 * c, tf, act=hip.ACT_GEGLU) if ctx.ln_fold_ff1 else self.ff1(ctx, ctx.layernorm(h, self.ln[2].g, self.ln[2].b))
@@ -232,9 +245,7 @@ class TBlock:
         y = ctx.layernorm(h, self.ln[1].g, self.ln[1].b)
         rec(y, 2)
         q = self.q2(ctx, y)
-        if self.kv_cache is None:                 # text is invariant over the denoising steps of one image
-            self.kv_cache = self.kv2(ctx, text)
-        kv = self.kv_cache
+        kv = self._text_kv(ctx, text)
         a = ctx.attention(q, kv[:, :c], kv[:, c:], self.heads, self.hd, tokens, text_len, batch)
         rec(a, 3)
         h = self.o2(ctx, a, residual=h)
@@ -320,6 +331,21 @@ class _CondNet:
             col += w.shape[0]
         self.temb_proj = Linear(self.ctx, None, None, w=torch.cat(ws, 0), b=torch.cat(bs, 0), quant=False)
         self._sd = None
+        self._finish_kv()
+
+    def _finish_kv(self):
+        """The to_k / to_v matrices of every transformer block of the net, concatenated: TBlock._text_kv.  f16 weights only (ctx.kv_group: A/B switch)."""
+        ctx = self.ctx
+        blocks = [b for t in self.transformers() for b in t.blocks]
+        self.kv_all, self._kv_out = None, None
+        if len(blocks) > 1 and not ctx.f32 and not ctx.w8 and all(b._kv_raw is not None for b in blocks):
+            self.kv_all = Linear(ctx, None, None, w=torch.cat([b._kv_raw for b in blocks], 0))
+            off = 0
+            for b in blocks:
+                b.kv_net, b.kv_slot = self, (off, off + 2 * b.c)
+                off += 2 * b.c
+        for b in blocks:
+            b._kv_raw = None
 
     def transformers(self):
         for layers, _ in self.down:
@@ -341,6 +367,7 @@ class _CondNet:
         self.add_emb = self.a2(ctx, self.a1(ctx, add_in, act=hip.ACT_SILU))
         for t in self.transformers():
             t.reset()
+        self._kv_out = None
 
     def time_rowbias(self, t_dev):
         """silu(time_emb + add_emb) -> all resnets' time projections in one GEMM.  t_dev: f32 [B, 1] on device."""
