@@ -171,6 +171,22 @@ class FieError(RuntimeError):
     pass
 
 
+def fold_layernorm_tables(w, bias, gamma, beta, geglu=False):
+    """LayerNorm folded into the Linear that consumes it:  LN(x) W^T + b = rstd * (x Wf^T - mean * S) + b'  with Wf = f16(W * gamma), S[n] = sum_k Wf[n, k]
+    (over the ROUNDED folded weights, so that x Wf^T - mean * S is exactly (x - mean) Wf^T), b' = W beta + b in fp32.  Returns (Wf [N, K] f16,
+    table [N, 2] fp32 = (S, b')), the table's rows in the packed column order (GEGLU: value / gate rows interleaved, as fie_pack_rows_f16 with interleave2)."""
+    w = w.float()
+    n = w.shape[0]
+    wf = (w * gamma.float()[None, :]).to(torch.float16)
+    b = w @ beta.float()
+    if bias is not None:
+        b = b + bias.float()
+    tab = torch.stack([wf.float().sum(1), b], 1)
+    if geglu:
+        tab = torch.stack([tab[: n // 2], tab[n // 2:]], 1).reshape(n, 2)
+    return wf, tab.contiguous()
+
+
 def _chk(rc):
     if rc != 0:
         raise FieError(f"libfie_hip error {rc}: {lib().fie_last_error().decode()}")
@@ -604,19 +620,10 @@ class Context:
 
     def fold_layernorm(self, w, bias, gamma, beta, geglu=False):
         """Prepares a Linear whose input is a LayerNorm for gemm_ln (include/fie.h: fie_gemm_ln_f16): the packed f16 matrix of W * gamma and the fp32 table
-        [(sum_k Wf[n, k], (W beta)[n] + bias[n])] in the packed column order.  The column sums run over the ROUNDED folded weights, so that
-        x Wf^T - mean * colsum is exactly (x - mean) Wf^T."""
-        w = w.to(self.device, torch.float32)
-        n, k = w.shape
-        wf = (w * gamma.to(self.device, torch.float32)[None, :]).to(torch.float16)
-        s = wf.float().sum(1)
-        b = w @ beta.to(self.device, torch.float32)
-        if bias is not None:
-            b = b + bias.to(self.device, torch.float32)
-        tab = torch.stack([s, b], 1)
-        if geglu:
-            tab = torch.stack([tab[: n // 2], tab[n // 2:]], 1).reshape(n, 2)
-        return self.pack_linear(wf, geglu=geglu, quant=False), tab.contiguous()
+        [(sum_k Wf[n, k], (W beta)[n] + bias[n])] in the packed column order (fold_layernorm_tables below: the algebra, device-free)."""
+        dev = lambda t: None if t is None else t.to(self.device)
+        wf, tab = fold_layernorm_tables(dev(w), dev(bias), dev(gamma), dev(beta), geglu=geglu)
+        return self.pack_linear(wf, geglu=geglu, quant=False), tab
 
     def gemm_ln(self, x, wp, n, tab, eps=1e-5, act=ACT_NONE, out=None):
         """out = act(LayerNorm(x) @ W^T + bias) with the LayerNorm folded into the GEMM (fold_layernorm prepared wp / tab); x: [M, K] un-normalised."""

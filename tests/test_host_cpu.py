@@ -124,3 +124,29 @@ def test_bench_reads_the_pmc_record_of_the_tile_it_ran(tmp_path):
     single = tmp_path / "single.json"                        # the single-record form of round 1
     single.write_text(json.dumps({"shape": {"M": 8, "N": 8, "K": 8}, "fetch_size_kib": 1000.0, "write_size_kib": 48.0, "source": ["x.csv"]}))
     assert bench.pmc_traffic("any kernel (tile code 1)", 8, 8, 8, path=str(single)) == (round((2 * 1000.0 + 48.0) * 1024 / 1e6, 1), ["x.csv"])
+
+
+@pytest.mark.parametrize("geglu", [False, True])
+def test_layernorm_fold_tables_reproduce_layernorm_plus_linear(geglu):
+    """The algebra behind fie_gemm_ln_f16 (hip.fold_layernorm_tables), on the CPU in float64: rstd * (x Wf^T - mean * S) + b' against LayerNorm -> Linear
+    with the f16-rounded folded weights, rows with a common offset several sigma large; GEGLU: the table follows the packed (value, gate interleaved) row order."""
+    import torch
+    import torch.nn.functional as F
+    from fie_amd.hip import fold_layernorm_tables
+    g = torch.Generator().manual_seed(3)
+    m, n, k = 37, 64, 128
+    x = (torch.randn(m, k, generator=g) * 2 + torch.randn(m, 1, generator=g) * 6).half()
+    w, b = (torch.randn(n, k, generator=g) / k ** 0.5).half(), (torch.randn(n, generator=g) * 0.1).half()
+    gamma, beta = (1 + 0.2 * torch.randn(k, generator=g)).half(), (0.1 * torch.randn(k, generator=g)).half()
+    wf, tab = fold_layernorm_tables(w, b, gamma, beta, geglu=geglu)
+    assert wf.dtype == torch.float16 and tab.dtype == torch.float32 and tab.shape == (n, 2)
+    xd = x.double()
+    mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    order = torch.stack([torch.arange(n // 2), torch.arange(n // 2) + n // 2], 1).reshape(-1) if geglu else torch.arange(n)      # packed row -> source row
+    folded = rstd * (xd @ wf.double()[order].t() - mean * tab[:, 0].double()[None, :]) + tab[:, 1].double()[None, :]
+    # the same LayerNorm -> Linear with the weights the kernel multiplies by (W * gamma rounded to f16; beta and bias exact)
+    ref = ((xd - mean) * rstd) @ wf.double()[order].t() + (w.double() @ beta.double() + b.double())[order][None, :]
+    assert (folded - ref).abs().max() < 1e-5                                          # the table is fp32
+    plain = F.layer_norm(xd, (k,), gamma.double(), beta.double(), 1e-5) @ w.double().t() + b.double()
+    assert (folded - plain[:, order]).abs().max() / plain.abs().max() < 2e-3          # what rounding W * gamma to f16 costs
