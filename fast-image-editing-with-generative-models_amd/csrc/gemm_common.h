@@ -648,6 +648,9 @@ int fie_gemm_init(void);           // same for the kernels of gemm_conv.hip
 // conv_halo.hip: the halo-resident 3x3 conv (tile code 71; 73 = with cycle stamps): a block = a 16x16 output patch x 128 channels
 int fie_launch_conv_halo(fie_ctx* ctx, fie_gemm::GemmArgs& a, int stamped);
 bool fie_conv_halo_ok(const fie_gemm::GemmArgs& a);
+// conv_thin.hip: 3x3 convs with at most 16 output channels (tile code 77): direct global -> VGPR operands, a wave = a 16-pixel strip x all channels
+int fie_launch_conv_thin(fie_ctx* ctx, fie_gemm::GemmArgs& a);
+bool fie_conv_thin_ok(const fie_gemm::GemmArgs& a);
 bool fie_conv_halo_gna_ok(const fie_gemm::GemmArgs& a);
 int fie_conv_halo_init(void);
 // gemm_w8.hip: fp8-weight ring kernels; code 62 = 256x128 (8 waves), 42 = 128x64, 43 = 64x64

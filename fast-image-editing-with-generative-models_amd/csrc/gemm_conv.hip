@@ -670,7 +670,7 @@ constexpr TileDim kTiles[] = {{1, 128, 128}, {2, 128, 64}, {3, 64, 64}, {42, 128
                               {51, 128, 128}, {61, 256, 256}, {62, 256, 128}, {81, 256, 256}, {82, 256, 256},
                               {63, 256, 320}, {95, 128, 128}, {96, 256, 128}, {97, 256, 128}, {98, 256, 128}, {94, 128, 64},
                               {52, 128, 128}, {47, 128, 96}, {54, 192, 128}, {46, 64, 64}, {44, 128, 64}, {48, 128, 80}, {64, 256, 320},
-                              {71, 256, 128}, {73, 256, 128}, {72, 256, 128}, {74, 256, 128}, {76, 256, 128}};
+                              {71, 256, 128}, {73, 256, 128}, {72, 256, 128}, {74, 256, 128}, {76, 256, 128}, {77, 64, 16}};
 
 // Heuristic tile code for a shape (the default; the autotuner below and the debug hooks can replace it).
 template <int MODE>
@@ -739,7 +739,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     for (const TileDim& d : kTiles)
         if (d.code == code) t = &d;
     FIE_REQUIRE(t != nullptr, "unknown tile code %d", code);
-    FIE_REQUIRE(code < 40 || dma_ok, "tile code %d: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)", code);
+    FIE_REQUIRE(code < 40 || code == 77 || dma_ok, "tile code %d: shape not eligible for the LDS-DMA kernels (operands >= 2 GiB, Cin %% 64 != 0 or K1 %% 64 != 0)", code);
     FIE_REQUIRE(!(a.taps2 && (code < 40 || a.w_scale)), "tile code %d: the 2x2 parity convs run on the f16 LDS-DMA kernels only", code);
     FIE_REQUIRE(!(MODE == 1 && a.A2 && (code < 40 || code == 81 || code == 82 || a.w_scale)), "tile code %d: conv + 1x1 side inputs run on the f16 ring kernels and the halo-resident kernel (72) only", code);
     FIE_REQUIRE(!((code >= 71 && code <= 76) && (MODE != 1 || !dma_ok || !fie_conv_halo_ok(a))), "tile code %d (halo-resident conv): stride-1 same-size 3x3 conv with H, W %% 16 == 0, Cin %% 64 == 0, f16 weights only", code);
@@ -783,7 +783,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
     a.probe = ctx->gemm_probe;
     a.epi_prefetch = ctx->epi_prefetch;
     a.stamps = (code == 97 || code == 98 || code == 94 || code == 73 || code == 74) ? ctx->gemm_stamps : nullptr;
-    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 90 ? "gemm3_kernel+prefetch" : code >= 80 ? "gemm8_kernel" : code >= 71 && code <= 76 ? (code == 71 || code == 73 ? "conv_halo_kernel" : "conv_halo2_kernel") : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
+    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s<%dx%d> (%s, tile code %d)", code >= 90 ? "gemm3_kernel+prefetch" : code >= 80 ? "gemm8_kernel" : code == 77 ? "conv_thin_kernel" : code >= 71 && code <= 76 ? (code == 71 || code == 73 ? "conv_halo_kernel" : "conv_halo2_kernel") : code >= 40 ? "gemm3_kernel" : "gemm_kernel",
              t->bm, t->bn, MODE == 1 ? "conv3x3" : "gemm", code);
     if (split > 1) snprintf(ctx->last_kernel + strlen(ctx->last_kernel) - 1, 24, ", split-K %d)", split);
     if (MODE == 1)
@@ -846,6 +846,7 @@ int run_code(fie_ctx* ctx, GemmArgs& a, int code, int order, bool dma_ok, int sp
         case 72: return fie_launch_conv_halo(ctx, a, 2);
         case 76: return fie_launch_conv_halo(ctx, a, 5);
         case 74: return fie_launch_conv_halo(ctx, a, 4);
+        case 77: return fie_launch_conv_thin(ctx, a);
         case 81: return fie_launch_gemm8(ctx, a, MODE == 1, 0);
         case 82: return fie_launch_gemm8(ctx, a, MODE == 1, 1);   // A/B: second DMA piece of a phase issued from inside the MFMA cluster (measured slower)
     }
@@ -993,6 +994,11 @@ int launch(fie_ctx* ctx, GemmArgs& a) {
         if (o.mode == (MODE == 1) && o.M == a.M && o.N == a.N && o.K == a.K) { decode(o.code); pinned = true; }
     }
     if (ctx->force_tile) { decode(ctx->force_tile); pinned = true; }
+    // at most 16 output channels (conv_out of the VAE / UNet, the conditioning embedding's first convs): the direct-load strip kernel of conv_thin.hip,
+    // by rule and without the tuner (one kernel family; profiles/r04_conv_thin.md).  fie_debug_tune_exclude("77") is the A/B switch.
+    if (MODE == 1 && !pinned && !ctx->gemm_probe && fie_conv_thin_ok(a) && a.M >= 131072 &&      // (the 128x128-latent conv_outs, K 2880 / 4608 on few strips: the ring tiles are faster)
+        std::find(std::begin(ctx->tune_exclude), std::end(ctx->tune_exclude), 77) == std::end(ctx->tune_exclude))
+        return run_code<MODE>(ctx, a, 77, 0, dma_ok, 1);
     if (ctx->autotune && !pinned && dma_ok && !ctx->gemm_probe) {      // 1: tune shapes not met before, 2: remembered shapes only
         const fie_tune_key key{MODE, a.M, a.N, a.K, a.K1, MODE == 1 ? a.stride * 2 + a.ups + 8 * a.taps2 + 16 * (a.A2 != nullptr) + 32 * (a.A3 != nullptr) : 0, a.w_scale == nullptr ? 0 : a.a_scale != 0.f ? 2 : 1};
         auto it = ctx->tuned.find(key);

@@ -1059,3 +1059,51 @@ def test_time_embed_fused(fie):
             for _ in range(50):
                 assert torch.equal(fie.time_embed(*dev, ws, add=add.to(DEV)), first)
         assert int(ws[-16:-8].view(torch.int32).abs().sum()) == 0          # both barrier counters back at zero
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,stride,pad_mode,act", [
+    (1, 512, 1024, 32, 4, 1, 0, "none"),        # row-reuse form, 8 rows per wave (the decoder's conv_out shape class)
+    (1, 512, 1024, 8, 16, 1, 0, "silu"),        # general form, 8 rows per wave (conditioning embedding: 3 -> 16 on the 8-channel padded image)
+    (2, 40, 24, 64, 12, 1, 0, "none"),          # row-reuse form, 2 rows per wave, ragged strip (24 = 16 + 8) and ragged row block
+    (2, 128, 128, 320, 4, 1, 0, "none"),        # the UNet's conv_out
+    (1, 50, 30, 16, 16, 2, 1, "silu"),          # general form: stride 2, asymmetric pad
+    (1, 33, 17, 96, 8, 2, 0, "none"),           # stride 2 with Cin % 32 == 0 (general form: the reuse form is stride 1 only)
+    (1, 19, 21, 24, 4, 1, 1, "none")])          # Cin % 32 != 0, a lane group straddles nothing (Cin % 8 == 0), K = 216 -> 7 steps, last one partly past K
+def test_thin_conv(fie, b, h, w, cin, cout, stride, pad_mode, act):
+    """3x3 convs with at most 16 output channels run on the direct-load strip kernel (csrc/conv_thin.hip, tile code 77) by rule: against an fp32
+    conv2d, and against an im2col tile of the launch table (a forced code goes past the rule)."""
+    from fie_amd import hip
+    x = rnd(b, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)
+    bias = rnd(cout, seed=3)
+    xi = x.float()
+    if pad_mode == 1:
+        xi = F.pad(xi, (0, 1, 0, 1))
+    ref = F.conv2d(xi, wt.float(), bias.float(), stride=stride, padding=1 if pad_mode == 0 else 0)
+    if act == "silu":
+        ref = F.silu(ref)
+    ref = ref * 0.5
+    xd, wp, bd = x.permute(0, 2, 3, 1).contiguous().to(DEV), fie.pack_conv3x3(wt.to(DEV)), bias.to(DEV)
+    kw = dict(stride=stride, pad_mode=pad_mode, bias=bd, scale=0.5, act=hip.ACT_SILU if act == "silu" else hip.ACT_NONE)
+    by_rule = b * ref.shape[2] * ref.shape[3] >= 131072                # smaller maps keep their ring tiles by rule: the code is forced for them
+    try:
+        if not by_rule:
+            fie.force_tile(77)
+        out = fie.conv3x3(xd, wp, cout, **kw)
+        assert "conv_thin_kernel" in hip.last_gemm_kernel(fie)
+        assert torch.equal(out, fie.conv3x3(xd, wp, cout, **kw))       # deterministic
+        o8 = fie.conv3x3(xd, wp, cout, ldc=8, **kw) if cout == 4 else None
+    finally:
+        fie.force_tile(0)
+    assert out.shape[1:3] == ref.shape[2:]
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 3e-3
+    try:
+        fie.force_tile(2)                                               # a pinned code goes past the thin-conv rule (as an override would)
+        old = fie.conv3x3(xd, wp, cout, **kw)
+        assert "conv_thin_kernel" not in hip.last_gemm_kernel(fie)
+    finally:
+        fie.force_tile(0)
+    assert rel_err(out, old) < 2e-3
+    # padded output rows (the decoder writes 3 channels as 4): ldc > Cout leaves the pad column alone
+    if o8 is not None:
+        assert torch.equal(o8[..., :4], out) and float(o8[..., 4:].abs().max()) == 0.0
