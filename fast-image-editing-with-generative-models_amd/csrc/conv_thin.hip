@@ -12,6 +12,7 @@
 // horizontal ones as one-lane DPP shifts of it, so a wave requests every input byte of its (ROWS + 2) x 18 pixel halo exactly once.  The general form (any Cin % 8 == 0, stride 1 / 2, either padding) walks
 // the im2col K axis in steps of 32: a lane's 8 k-values never straddle a tap because Cin % 8 == 0.
 // Sums: fp32 accumulators, K order differs from the im2col tiles (last-bit differences in f16 against them; deterministic).
+#include <stdlib.h>
 #include "fie_internal.h"
 #include "gemm_common.h"
 
@@ -26,16 +27,18 @@ __device__ __forceinline__ f16x8 ld8_or_zero(const half_t* p, bool ok) {
 
 // block = 4 waves stacked in y: a 16 x (4 ROWS) output patch of one image.  grid = B * ceil(OH / (4 ROWS)) * ceil(OW / 16), remapped so that
 // consecutive patches (which share halo columns / rows) run on one XCD.
-template <int ROWS, bool REUSE>
+template <int ROWS, int FORM>      // FORM 0: general, 1: row reuse with the halo pixels in a second fragment, 2: row reuse on overlapping 14-pixel strips
 __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, kq = lane >> 4;
-    const int tiles_x = (p.OW + 15) >> 4, tiles_y = (p.OH + 4 * ROWS - 1) / (4 * ROWS);
+    constexpr bool REUSE = FORM != 0;
+    constexpr int SW = FORM == 2 ? 14 : 16;                            // output pixels per strip
+    const int tiles_x = (p.OW + SW - 1) / SW, tiles_y = (p.OH + 4 * ROWS - 1) / (4 * ROWS);
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = bid / (tiles_x * tiles_y);
     bid -= b * tiles_x * tiles_y;
     const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
-    const int ox = tx * 16 + px;
+    const int ox = FORM == 2 ? tx * 14 - 1 + px : tx * 16 + px;       // FORM 2: lanes 0 / 15 hold the strip's halo columns and store nothing
     const int oy0 = ty * 4 * ROWS + wave * ROWS;
     const half_t* X = p.A1 + (int64_t)b * p.H * p.W * p.Cin;
     const half_t* wrow = p.Wt + (int64_t)px * p.ldw + kq * 8;         // weight row = output channel px (rows past N are zero in the packed matrix)
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p) {
         // lines came back three times, a working set apart that no cache level holds (first form: 204 us on the decoder's conv_out).
         const int nch = p.Cin >> 5;
         const int x0 = tx * 16, ex = px == 0 ? x0 - 1 : x0 + 16;
-        const bool vc = ox < p.W, ve = (px == 0 || px == 15) && ex >= 0 && ex < p.W;
+        const bool vc = ox >= 0 && ox < p.W, ve = FORM == 1 && (px == 0 || px == 15) && ex >= 0 && ex < p.W;
         const half_t* xcen = X + (int64_t)(vc ? ox : 0) * p.Cin + kq * 8;
         const half_t* xedg = X + (int64_t)(ve ? ex : 0) * p.Cin + kq * 8;
         const int64_t row_ld = (int64_t)p.W * p.Cin;
@@ -66,14 +69,14 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p) {
                 const int iy = oy0 + ri - 1;
                 const int64_t ro = (int64_t)(iy >= 0 && iy < p.H ? iy : 0) * row_ld + c * 32;       // clamped: always in range, zeroed below
                 xa[ri] = *reinterpret_cast<const u32x4*>(xcen + ro);
-                xb[ri] = *reinterpret_cast<const u32x4*>(xedg + ro);
+                if constexpr (FORM == 1) xb[ri] = *reinterpret_cast<const u32x4*>(xedg + ro);
             }
             __builtin_amdgcn_sched_barrier(0);      // every load of the chunk in flight before the first MFMA (left alone the scheduler sinks them between the MFMAs, six at a time behind vmcnt(0) waits)
 #pragma unroll
             for (int ri = 0; ri < ROWS + 2; ++ri) {
                 const int iy = oy0 + ri - 1;
                 const bool rv = iy >= 0 && iy < p.H;                        // wave-uniform
-                const u32x4 xc = rv && vc ? xa[ri] : zero4, xe = rv && ve ? xb[ri] : zero4;
+                const u32x4 xc = rv && vc ? xa[ri] : zero4, xe = FORM == 1 && rv && ve ? xb[ri] : zero4;      // FORM 2: the lane without an in-row source gets zero, and its column is never stored
                 u32x4 xl, xr;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p) {
 
     // lane: channels kq * 4 .. + 3 of pixel (b, oy0 + r, ox).  Epilogue order as gemm_common.h: bias, activation, scale.
     const int n0 = kq * 4;
-    if (n0 >= p.N || ox >= p.OW) return;
+    if (n0 >= p.N || ox >= p.OW || (FORM == 2 && (px == 0 || px == 15))) return;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
         const f16x4 b4 = *reinterpret_cast<const f16x4*>(p.bias + n0);
@@ -150,20 +153,32 @@ int fie_launch_conv_thin(fie_ctx* ctx, GemmArgs& a) {
     FIE_REQUIRE(fie_conv_thin_ok(a), "thin conv (tile code 77): Cout <= 16, plain bias / SiLU epilogue, f16 weights, no side inputs only");
     const int B = a.M / (a.OH * a.OW);
     const bool reuse = a.stride == 1 && a.Cin % 32 == 0 && a.pt == 1 && a.pl == 1;
-    const int tiles_x = (a.OW + 15) / 16;
+    // row reuse: overlapping 14-pixel strips (no halo fragment: half the load instructions, 40 VGPRs less) against 16-pixel strips with the halo pixels in a
+    // second fragment: profiles/r04_conv_thin.md
+    static const int form_env = getenv("FIE_THIN_FORM") ? atoi(getenv("FIE_THIN_FORM")) : 2;      // A/B knob of tools/conv_thin_time.py (1 / 2)
+    const int form = reuse ? (form_env == 1 ? 1 : 2) : 0;
+    const int sw = form == 2 ? 14 : 16;
+    const int tiles_x = (a.OW + sw - 1) / sw;
     // 8 rows per wave while that still gives every CU a few blocks, else 2 (small maps).  4 rows per wave (3 waves per SIMD instead of 2) measured
     // slower on the decoder's conv_out: 105 against 92 us (profiles/r04_conv_thin.md)
     const int64_t blocks8 = (int64_t)B * ((a.OH + 31) / 32) * tiles_x;
-    const int rows = blocks8 >= 4 * (int64_t)ctx->num_cus ? 8 : 2;
+    int rows = blocks8 >= 4 * (int64_t)ctx->num_cus ? 8 : 2;
+    static const int rows_env = getenv("FIE_THIN_ROWS") ? atoi(getenv("FIE_THIN_ROWS")) : 0;
+    if (rows == 8 && form == 2 && (rows_env == 6 || rows_env == 4)) rows = rows_env;
     const int64_t grid = (int64_t)B * ((a.OH + 4 * rows - 1) / (4 * rows)) * tiles_x;
     FIE_REQUIRE(grid < (1ll << 31), "thin conv: grid too large");
     const dim3 g((unsigned)grid), blk(256);
-    if (reuse) {
-        if (rows == 8) fie_launch(ctx, (conv_thin_kernel<8, true>), g, blk, 0, a);
-        else fie_launch(ctx, (conv_thin_kernel<2, true>), g, blk, 0, a);
+    if (form == 2) {
+        if (rows == 8) fie_launch(ctx, (conv_thin_kernel<8, 2>), g, blk, 0, a);
+        else if (rows == 6) fie_launch(ctx, (conv_thin_kernel<6, 2>), g, blk, 0, a);
+        else if (rows == 4) fie_launch(ctx, (conv_thin_kernel<4, 2>), g, blk, 0, a);
+        else fie_launch(ctx, (conv_thin_kernel<2, 2>), g, blk, 0, a);
+    } else if (form == 1) {
+        if (rows == 8) fie_launch(ctx, (conv_thin_kernel<8, 1>), g, blk, 0, a);
+        else fie_launch(ctx, (conv_thin_kernel<2, 1>), g, blk, 0, a);
     } else {
-        if (rows == 8) fie_launch(ctx, (conv_thin_kernel<8, false>), g, blk, 0, a);
-        else fie_launch(ctx, (conv_thin_kernel<2, false>), g, blk, 0, a);
+        if (rows == 8) fie_launch(ctx, (conv_thin_kernel<8, 0>), g, blk, 0, a);
+        else fie_launch(ctx, (conv_thin_kernel<2, 0>), g, blk, 0, a);
     }
     FIE_LAUNCH_CHECK();
     return FIE_OK;
