@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Thin 3x3 convs (Cout <= 16: csrc/conv_thin.hip, tile code 77) against the im2col tile the rule gave them before (fie_debug_tune_exclude("77")),
-per shape of one edit, inputs rotated over > 256 MB of copies (cold, as inside the network).  usage: tools/conv_thin_time.py"""
+per shape of one edit, inputs rotated over > 256 MB of copies (cold, as inside the network).
+usage: tools/conv_thin_time.py [substring of the shape name] [thin-only]     (thin-only: no launches of the other tile: for rocprofv3 --pmc passes)"""
 import os
 import sys
 
@@ -32,7 +33,11 @@ shapes = [(1, 1024, 1024, 128, 4, 4, 1, 0, "VAE decoder conv_out"), (1, 1024, 10
           (1, 1024, 1024, 8, 16, 16, 1, 1, "cond. embedding 3(8) -> 16"), (2, 128, 128, 320, 4, 4, 1, 0, "UNet conv_out"),
           (1, 128, 128, 512, 8, 8, 1, 0, "VAE encoder conv_out")]
 total = [0.0, 0.0]
+want = sys.argv[1] if len(sys.argv) > 1 else ""
+thin_only = len(sys.argv) > 2 and sys.argv[2] == "thin-only"
 for b, h, w, cin, cout, ldc, stride, act, what in shapes:
+    if want not in what:
+        continue
     nbytes = b * h * w * cin * 2
     copies = max(2, min(24, int(600e6 / nbytes) + 1))
     xs = [torch.randn(b, h, w, cin, generator=g, device=DEV, dtype=torch.float16) for _ in range(copies)]
@@ -44,12 +49,15 @@ for b, h, w, cin, cout, ldc, stride, act, what in shapes:
         return ctx.conv3x3(xs[i % copies], wp, cout, out=out, stride=stride, bias=bias, act=act, ldc=ldc)
 
     res = []
-    for excl in ("", "77", "", "77"):
+    for excl in (("", "") if thin_only else ("", "77", "", "77")):
         ctx.tune_exclude(excl)
         run(0)
         name = hip.last_gemm_kernel(ctx)
         res.append((timed(run, 20), name))
     ctx.tune_exclude("")
+    if thin_only:
+        print(f"{what}: thin {min(r[0] for r in res):.1f} us")
+        continue
     t_new, t_old = min(res[0][0], res[2][0]), min(res[1][0], res[3][0])
     total[0] += t_new
     total[1] += t_old
