@@ -8,10 +8,9 @@
 // alone is ~55 us.  Here a wave owns a 16-pixel-wide strip of ROWS output rows and ALL output channels: the MFMA is issued transposed
 // (A = 16 weight rows, B = 16 pixels) so that a lane ends up with 4 consecutive channels of one pixel (one 8-byte store, 128 contiguous bytes per
 // 16 pixels at ldc = 4), operands go global -> VGPR directly (no LDS, no barrier: nothing is shared between waves but cache lines), and in the
-// REUSE form (stride 1, pad 1, Cin % 64 == 0) an input fragment loaded once feeds all nine taps: the three vertical ones of three output rows, the
-// horizontal ones as one-lane DPP shifts of it on strips that overlap by their halo columns, and a lane takes both halves of its pixel's 128-byte line
-// back to back, so a wave requests every line of its (ROWS + 2) x 16 pixel halo exactly once, whole.  The general form (any Cin % 8 == 0, stride 1 / 2,
-// either padding) walks the im2col K axis in steps of 32: a lane's 8 k-values never straddle a tap because Cin % 8 == 0.
+// REUSE form (stride 1, pad 1, Cin % 32 == 0) an input fragment loaded once feeds all nine taps: the three vertical ones of three output rows, the
+// horizontal ones as one-lane DPP shifts of it, so a wave requests every input byte of its (ROWS + 2) x 18 pixel halo exactly once.  The general form (any Cin % 8 == 0, stride 1 / 2, either padding) walks
+// the im2col K axis in steps of 32: a lane's 8 k-values never straddle a tap because Cin % 8 == 0.
 // Sums: fp32 accumulators, K order differs from the im2col tiles (last-bit differences in f16 against them; deterministic).
 #include "fie_internal.h"
 #include "gemm_common.h"
@@ -27,18 +26,16 @@ __device__ __forceinline__ f16x8 ld8_or_zero(const half_t* p, bool ok) {
 
 // block = 4 waves stacked in y: a 16 x (4 ROWS) output patch of one image.  grid = B * ceil(OH / (4 ROWS)) * ceil(OW / 16), remapped so that
 // consecutive patches (which share halo columns / rows) run on one XCD.
-template <int ROWS, int FORM>      // FORM 0: general, 2: row reuse on overlapping 14-pixel strips
+template <int ROWS, bool REUSE>
 __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, kq = lane >> 4;
-    constexpr bool REUSE = FORM != 0;
-    constexpr int SW = FORM == 2 ? 14 : 16;                            // output pixels per strip
-    const int tiles_x = (p.OW + SW - 1) / SW, tiles_y = (p.OH + 4 * ROWS - 1) / (4 * ROWS);
+    const int tiles_x = (p.OW + 15) >> 4, tiles_y = (p.OH + 4 * ROWS - 1) / (4 * ROWS);
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = bid / (tiles_x * tiles_y);
     bid -= b * tiles_x * tiles_y;
     const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
-    const int ox = FORM == 2 ? tx * 14 - 1 + px : tx * 16 + px;       // FORM 2: lanes 0 / 15 hold the strip's halo columns and store nothing
+    const int ox = tx * 16 + px;
     const int oy0 = ty * 4 * ROWS + wave * ROWS;
     const half_t* X = p.A1 + (int64_t)b * p.H * p.W * p.Cin;
     const half_t* wrow = p.Wt + (int64_t)px * p.ldw + kq * 8;         // weight row = output channel px (rows past N are zero in the packed matrix)
@@ -47,55 +44,50 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p) {
     for (int r = 0; r < ROWS; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if constexpr (REUSE) {
-        // stride 1, pad 1, Cin % 64 == 0: input row iy = oy + ky - 1, input column ix = ox + kx - 1.  Strips OVERLAP: lane px holds column 14 tx - 1 + px, so lanes
-        // 0 / 15 carry the strip's halo columns (and store nothing) and the kx = 0 / 2 operands are the centre fragment shifted one lane inside its DPP
-        // row (px = lane & 15 IS the row position; the lane without an in-row source gets zero, in a column that is never stored).  Per iteration a lane
-        // loads BOTH 64-byte halves of its pixel's 128-byte line for the ROWS + 2 input rows, back to back, and every fragment feeds the three vertical
-        // taps of three output rows: each input line is requested once per wave, whole.  What this replaced: profiles/r04_conv_thin.md.
-        const int nc2 = p.Cin >> 6;
-        const bool vc = ox >= 0 && ox < p.W;
+        // stride 1, pad 1: input row iy = oy + ky - 1, input column ix = ox + kx - 1.  Per 32-channel chunk a lane loads ITS pixel of the ROWS + 2 input
+        // rows once (xc) and the strip's two halo pixels ride in lanes px == 0 (column x0 - 1) and px == 15 (column x0 + 16) of a second fragment (xe);
+        // the kx = 0 / 2 operands are the centre fragment shifted by one lane within its DPP row (px = lane & 15 IS the row position; the lane with
+        // no in-row source keeps `old` = the halo pixel).  Every input byte is requested once per wave: with kx as a loop around the loads the same
+        // lines came back three times, a working set apart that no cache level holds (first form: 204 us on the decoder's conv_out).
+        const int nch = p.Cin >> 5;
+        const int x0 = tx * 16, ex = px == 0 ? x0 - 1 : x0 + 16;
+        const bool vc = ox < p.W, ve = (px == 0 || px == 15) && ex >= 0 && ex < p.W;
         const half_t* xcen = X + (int64_t)(vc ? ox : 0) * p.Cin + kq * 8;
+        const half_t* xedg = X + (int64_t)(ve ? ex : 0) * p.Cin + kq * 8;
         const int64_t row_ld = (int64_t)p.W * p.Cin;
         const u32x4 zero4 = {0u, 0u, 0u, 0u};
-        for (int c2 = 0; c2 < nc2; ++c2) {
+        for (int c = 0; c < nch; ++c) {
             f16x8 w[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) w[t] = ld8_or_zero(wrow + t * p.Cin + c2 * 64, px < p.N);        // first half's weights ahead of the activations (vmcnt counts in order)
-            u32x4 xa[2][ROWS + 2];
+            for (int t = 0; t < 9; ++t) w[t] = ld8_or_zero(wrow + t * p.Cin + c * 32, px < p.N);
+            u32x4 xa[ROWS + 2], xb[ROWS + 2];
 #pragma unroll
             for (int ri = 0; ri < ROWS + 2; ++ri) {
                 const int iy = oy0 + ri - 1;
-                const int64_t ro = (int64_t)(iy >= 0 && iy < p.H ? iy : 0) * row_ld + c2 * 64;      // clamped: always in range, zeroed below
-                xa[0][ri] = *reinterpret_cast<const u32x4*>(xcen + ro);
-                xa[1][ri] = *reinterpret_cast<const u32x4*>(xcen + ro + 32);
+                const int64_t ro = (int64_t)(iy >= 0 && iy < p.H ? iy : 0) * row_ld + c * 32;       // clamped: always in range, zeroed below
+                xa[ri] = *reinterpret_cast<const u32x4*>(xcen + ro);
+                xb[ri] = *reinterpret_cast<const u32x4*>(xedg + ro);
             }
-            __builtin_amdgcn_sched_barrier(0);      // every load of the iteration in flight before the first MFMA (left alone the scheduler sinks them between the MFMAs, six at a time behind vmcnt(0) waits)
+            __builtin_amdgcn_sched_barrier(0);      // every load of the chunk in flight before the first MFMA (left alone the scheduler sinks them between the MFMAs, six at a time behind vmcnt(0) waits)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h == 1) {
+            for (int ri = 0; ri < ROWS + 2; ++ri) {
+                const int iy = oy0 + ri - 1;
+                const bool rv = iy >= 0 && iy < p.H;                        // wave-uniform
+                const u32x4 xc = rv && vc ? xa[ri] : zero4, xe = rv && ve ? xb[ri] : zero4;
+                u32x4 xl, xr;
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) w[t] = ld8_or_zero(wrow + t * p.Cin + c2 * 64 + 32, px < p.N);
+                for (int d = 0; d < 4; ++d) {
+                    xl[d] = (unsigned)__builtin_amdgcn_update_dpp((int)xe[d], (int)xc[d], 0x111, 0xF, 0xF, false);    // row_shr:1: lane px <- px - 1
+                    xr[d] = (unsigned)__builtin_amdgcn_update_dpp((int)xe[d], (int)xc[d], 0x101, 0xF, 0xF, false);    // row_shl:1: lane px <- px + 1
                 }
+                const f16x8 fl = __builtin_bit_cast(f16x8, xl), fc = __builtin_bit_cast(f16x8, xc), fr = __builtin_bit_cast(f16x8, xr);
 #pragma unroll
-                for (int ri = 0; ri < ROWS + 2; ++ri) {
-                    const int iy = oy0 + ri - 1;
-                    const bool rv = iy >= 0 && iy < p.H;                    // wave-uniform
-                    const u32x4 xc = rv && vc ? xa[h][ri] : zero4;
-                    u32x4 xl, xr;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        xl[d] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xc[d], 0x111, 0xF, 0xF, true);      // row_shr:1: lane px <- px - 1
-                        xr[d] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xc[d], 0x101, 0xF, 0xF, true);      // row_shl:1: lane px <- px + 1
-                    }
-                    const f16x8 fl = __builtin_bit_cast(f16x8, xl), fc = __builtin_bit_cast(f16x8, xc), fr = __builtin_bit_cast(f16x8, xr);
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int r = ri - ky;                              // output row fed by input row ri through tap row ky
-                        if (r >= 0 && r < ROWS) {
-                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ky * 3 + 0], fl, acc[r], 0, 0, 0);
-                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ky * 3 + 1], fc, acc[r], 0, 0, 0);
-                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ky * 3 + 2], fr, acc[r], 0, 0, 0);
-                        }
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int r = ri - ky;                                  // output row fed by input row ri through tap row ky
+                    if (r >= 0 && r < ROWS) {
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ky * 3 + 0], fl, acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ky * 3 + 1], fc, acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ky * 3 + 2], fr, acc[r], 0, 0, 0);
                     }
                 }
             }
@@ -123,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const GemmArgs p) {
 
     // lane: channels kq * 4 .. + 3 of pixel (b, oy0 + r, ox).  Epilogue order as gemm_common.h: bias, activation, scale.
     const int n0 = kq * 4;
-    if (n0 >= p.N || ox >= p.OW || (FORM == 2 && (px == 0 || px == 15))) return;
+    if (n0 >= p.N || ox >= p.OW) return;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
         const f16x4 b4 = *reinterpret_cast<const f16x4*>(p.bias + n0);
@@ -157,23 +149,21 @@ bool fie_conv_thin_ok(const GemmArgs& a) {
 int fie_launch_conv_thin(fie_ctx* ctx, GemmArgs& a) {
     FIE_REQUIRE(fie_conv_thin_ok(a), "thin conv (tile code 77): Cout <= 16, plain bias / SiLU epilogue, f16 weights, no side inputs only");
     const int B = a.M / (a.OH * a.OW);
-    const bool reuse = a.stride == 1 && a.Cin % 64 == 0 && a.pt == 1 && a.pl == 1;
-    const int form = reuse ? 2 : 0;
-    const int sw = form == 2 ? 14 : 16;
-    const int tiles_x = (a.OW + sw - 1) / sw;
-    // 8 rows per wave while that still gives every CU a few blocks, else 2 (small maps).  6 / 4 rows per wave measured slower on the decoder's conv_out
-    // (92 / 99 against 86 us: more halo rows re-read per output row; occupancy is 2 waves per SIMD either way down to 6)
+    const bool reuse = a.stride == 1 && a.Cin % 32 == 0 && a.pt == 1 && a.pl == 1;
+    const int tiles_x = (a.OW + 15) / 16;
+    // 8 rows per wave while that still gives every CU a few blocks, else 2 (small maps).  4 rows per wave (3 waves per SIMD instead of 2) measured
+    // slower on the decoder's conv_out: 105 against 92 us (profiles/r04_conv_thin.md)
     const int64_t blocks8 = (int64_t)B * ((a.OH + 31) / 32) * tiles_x;
     const int rows = blocks8 >= 4 * (int64_t)ctx->num_cus ? 8 : 2;
     const int64_t grid = (int64_t)B * ((a.OH + 4 * rows - 1) / (4 * rows)) * tiles_x;
     FIE_REQUIRE(grid < (1ll << 31), "thin conv: grid too large");
     const dim3 g((unsigned)grid), blk(256);
-    if (form == 2) {
-        if (rows == 8) fie_launch(ctx, (conv_thin_kernel<8, 2>), g, blk, 0, a);
-        else fie_launch(ctx, (conv_thin_kernel<2, 2>), g, blk, 0, a);
+    if (reuse) {
+        if (rows == 8) fie_launch(ctx, (conv_thin_kernel<8, true>), g, blk, 0, a);
+        else fie_launch(ctx, (conv_thin_kernel<2, true>), g, blk, 0, a);
     } else {
-        if (rows == 8) fie_launch(ctx, (conv_thin_kernel<8, 0>), g, blk, 0, a);
-        else fie_launch(ctx, (conv_thin_kernel<2, 0>), g, blk, 0, a);
+        if (rows == 8) fie_launch(ctx, (conv_thin_kernel<8, false>), g, blk, 0, a);
+        else fie_launch(ctx, (conv_thin_kernel<2, false>), g, blk, 0, a);
     }
     FIE_LAUNCH_CHECK();
     return FIE_OK;

@@ -1063,7 +1063,7 @@ def test_time_embed_fused(fie):
 
 @pytest.mark.parametrize("b,h,w,cin,cout,stride,pad_mode,act", [
     (1, 512, 1024, 64, 4, 1, 0, "none"),        # row-reuse form, 8 rows per wave (the decoder's conv_out shape class)
-    (1, 256, 1024, 32, 8, 1, 0, "none"),        # Cin % 64 != 0 at stride 1: general form
+    (1, 256, 1024, 32, 8, 1, 0, "none"),        # one 32-channel chunk
     (1, 512, 1024, 8, 16, 1, 0, "silu"),        # general form, 8 rows per wave (conditioning embedding: 3 -> 16 on the 8-channel padded image)
     (2, 40, 24, 64, 12, 1, 0, "none"),          # row-reuse form, 2 rows per wave, ragged strip (24 = 16 + 8) and ragged row block
     (2, 128, 128, 320, 4, 1, 0, "none"),        # the UNet's conv_out
